@@ -1,0 +1,212 @@
+/*
+ * libneuspeech_hip — C ABI of the MI355X (gfx950) hot path of NeuSpeech's
+ * Whisper-based MEG->text training / decoding.
+ *
+ * The reference (NeuSpeech/NeuSpeech1, pure Python) has no FFI: its hot path is
+ * torch.nn / HuggingFace / PEFT module calls.  Each entry point below cites the
+ * reference call site (file:line, relative to the reference tree, or HF: for
+ * transformers' modeling_whisper.py) whose arithmetic it replaces.  A
+ * maintainer binds these with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; the caller owns all
+ *    memory (the library never allocates device memory nor retains pointers).
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream).  All
+ *    functions only enqueue work; none synchronises.
+ *  - return value: 0 = ok, <0 = ns_status; text via ns_last_error()
+ *    (thread-local).
+ *  - fp16 tensors are IEEE binary16 ("f16"), accumulations are fp32.
+ *  - activations are TOKEN-MAJOR: (rows = batch*time, cols = channels).
+ */
+#ifndef NEUSPEECH_HIP_H
+#define NEUSPEECH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NS_OK = 0,
+  NS_ERR_BAD_ARG = -1,
+  NS_ERR_UNSUPPORTED = -2,
+  NS_ERR_HIP = -3
+} ns_status;
+
+int ns_version(void);                 /* ABI version, currently 1 */
+const char* ns_last_error(void);      /* thread-local, never NULL */
+
+/* ------------------------------------------------------------------------
+ * Row maps.  A logical row index m of a matrix is located at element offset
+ *     (m / seg_rows) * seg_stride + (m % seg_rows) * ld          seg_rows > 0
+ *     m * ld                                                      seg_rows == 0
+ * This lets one GEMM walk a (B, T+2, C) halo-padded activation as the
+ * overlapping-row im2col view of a k=3 Conv1d (ld = stride*C, K = 3*C) with no
+ * im2col buffer.  seg_rows must be a multiple of 4.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int64_t seg_stride;
+  int32_t seg_rows;
+  int32_t ld;
+} ns_rowmap;
+
+enum {
+  NS_GEMM_GELU = 1,      /* G16 / H32 take gelu(round16(acc+bias)) */
+  NS_GEMM_DGELU = 2,     /* C16 = round16(round16(acc) * gelu'(P16)) */
+  NS_GEMM_TN = 4,        /* operands are reduction-major: A is (Kred x M) as X[m_red][m], see ns_gemm */
+  NS_GEMM_ATOMIC32 = 8,  /* C32 += acc (fp32 atomics), for split reductions */
+  NS_GEMM_DROP_A = 16    /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection) */
+};
+
+/*
+ * ns_gemm: C = A * B^T (+ A2 * B2^T) with fused epilogues, fp16 in / fp32 acc.
+ *
+ * NT form (default):  A (M x K) rows via `am`, B (N x K) row-major ldb.
+ *   Replaces torch.nn.Linear / Conv1d forward+dgrad at
+ *   utils/model_utils.py:13-15, utils/load_model.py:410-411 (conv stem),
+ *   HF:modeling_whisper.py:279-282,309,332-333,354 (q/k/v/out), :403-405
+ *   (fc1/fc2), utils/load_model.py:1047 (proj_out) and their autograd
+ *   backward; the optional second product is the LoRA side path
+ *   (finetune.py:205-212, peft lora.Linear.forward).
+ *   If a2_ngroup > 0, A2's column window starts at ((n0 / a2_ngroup) * K2)
+ *   for the output-column tile starting at n0 (fused q|k|v with separate
+ *   LoRA-A outputs side by side).
+ *
+ * TN form (NS_GEMM_TN): C[n][k] = sum_m A[m][n] * B[m][k], i.e. both operands
+ *   are stored reduction-major (A = dY (Mred x N) rows via `am`, B = X
+ *   (Mred x K) rows via `bm`); M in the descriptor is the number of OUTPUT
+ *   rows (N of dY), N the number of output columns, K the reduction length.
+ *   The reduction is split over gridDim.z = `splits` chunks and accumulated
+ *   with fp32 atomics into C32 (which the caller zeroes).  Replaces the weight
+ *   gradients autograd produces for the trainable Conv1d / LoRA tensors
+ *   (finetune.py:202,205-212).
+ *
+ * Epilogue, per element, v = acc (+ bias[n]):
+ *   v16 = round16(v);  DGELU: v16 = round16(v16 * gelu'(P16))
+ *   C16 <- v16 (if C16);  g = GELU ? round16(gelu(v16)) : v16;  G16 <- g
+ *   H32 <- R32 + g (+ pos[m % pos_rows][n])  (if H32)
+ *   C32 (+)= v (if C32)
+ */
+typedef struct {
+  const void* A;  ns_rowmap am;  int32_t K;
+  const void* B;  ns_rowmap bm;              /* NT: bm.ld = ldb, seg_rows = 0 */
+  const void* A2; ns_rowmap am2; int32_t K2; /* optional second product */
+  const void* B2; int32_t ldb2;
+  int32_t a2_ngroup;
+  int32_t M, N;
+  const float* bias;
+  void* C16;       ns_rowmap c16m;
+  void* G16;       ns_rowmap g16m;
+  const void* P16; ns_rowmap p16m;
+  const float* R32; float* H32; ns_rowmap h32m;
+  const float* pos; int32_t pos_rows;
+  float* C32; int32_t ldc32;
+  int32_t flags;
+  int32_t splits;           /* TN only: reduction split count (>=1) */
+  /* LoRA-dropout hook (NT dgrad): if drop_p > 0 the (A2,B2) product is formed
+     FIRST, multiplied element-wise by keep(seed,row,col)/(1-p), and the main
+     product accumulates on top.  For TN the mask multiplies operand B. */
+  float drop_p; uint32_t drop_seed;
+  float alpha;              /* acc is multiplied by alpha first (0 is read as 1) */
+} ns_gemm_desc;
+
+int ns_gemm(const ns_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm over the fp32 residual stream (eps 1e-5, affine), one row = d
+ * channels.  Replaces nn.LayerNorm at HF:modeling_whisper.py:392,402,
+ * utils/load_model.py:468 (encoder final) and the decoder's three per layer.
+ * fwd: y16 (and/or y32) = LN(x); mean/rstd (fp32, rows) are saved for bwd.
+ * bwd: dx = LN'(dy) with frozen gamma/beta (no parameter grads: the reference
+ *      freezes them, finetune.py:176); dx32 = dres + dx (residual-gradient
+ *      accumulate, dres may be NULL), dx16 = round16(dx32) for the next GEMM.
+ * d must be a multiple of 256 and <= 1280.
+ * ---------------------------------------------------------------------- */
+int ns_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32,
+                     float* mean, float* rstd, int rows, int d, float eps, void* stream);
+int ns_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, const float* dres, float* dx32, void* dx16, int rows, int d,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * ns_signal_pack: the MEG batch (B, ch, T) fp32 exactly as the collator emits
+ * it (utils/data_utils.py:191-193) -> (B, T+2, Cp) fp16 token-major with zero
+ * halo rows 0 and T+1 and zero channels [ch, Cp); Cp % 64 == 0.  This is the
+ * only full-size read of the signal tensor (coalesced along T).
+ * ---------------------------------------------------------------------- */
+int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream);
+
+/* h32[row] = E32[ids[row]] + P32[pos0 + row % L]; pos0_dev (optional) overrides
+ * pos0 from device memory (decode step counter).  utils/load_model.py:645,668-673 */
+int ns_embed_pos(const int64_t* ids, const float* E32, const float* P32, float* h32, int rows, int L, int d,
+                 int pos0, const int* pos0_dev, void* stream);
+
+/* conv-stem backward seams (the GELUs at utils/model_utils.py:14 and
+ * utils/load_model.py:410-411): out16[map(row)] = round16(a16[row] * gelu'(pre16[row]));
+ * bias gradient out32[c] += alpha * sum_rows a16[row][c] (fp32 atomics). */
+int ns_dgelu_mul(const void* a16, const void* pre16, void* out16, const ns_rowmap* out_map, int rows, int cols,
+                 void* stream);
+int ns_colsum(const void* a16, float* out32, int rows, int cols, int ld, float alpha, void* stream);
+
+/* batched fp32 -> fp16 operand refresh after an optimizer step:
+ * dst[r][c] = scale*src[r][c]  or (transpose) dst[c][r] = scale*src[r][c] */
+typedef struct {
+  const void* src; void* dst;
+  int32_t rows, cols, ld_src, ld_dst;
+  float scale; int32_t transpose;
+} ns_cast_job;
+int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused attention, head_dim 64.  Row (b*L + i) of each token-major matrix,
+ * head h at column h*64.  q must be pre-scaled by head_dim^-0.5 (HF folds it
+ * into q_proj's output, modeling_whisper.py:309).  causal: key j is visible to
+ * query i iff j <= i + (Lk - Lq).  LSE/Delta are (B, H, Lq) fp32.
+ * Replaces HF:modeling_whisper.py:215-238 and its backward.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const void *Q, *K, *V; void* O;
+  const void* dO; void *dQ, *dK, *dV;
+  float* LSE; float* Delta;
+  int32_t B, H, Lq, Lk, head_dim;
+  int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int32_t causal;
+} ns_attn_desc;
+int ns_attn_fwd(const ns_attn_desc* d, void* stream);
+int ns_attn_bwd(const ns_attn_desc* d, void* stream);   /* writes dQ, dK, dV and Delta */
+
+/* ------------------------------------------------------------------------
+ * Cross-entropy on fp16 logits (rows x ldv, first V columns valid), labels
+ * int64 with -100 = ignore: loss = mean over valid rows (fp32, *loss_dev),
+ * dlogits16 = round16((softmax - onehot) * loss_scale / n_valid) (may alias
+ * logits16; NULL = forward only).  utils/load_model.py:1049-1054.
+ * ---------------------------------------------------------------------- */
+int ns_cross_entropy(const void* logits16, const int64_t* labels, int rows, int V, int ldv, float* row_loss,
+                     void* dlogits16, int* nvalid_dev, const float* loss_scale_dev, float* loss_dev,
+                     void* stream);
+/* first-index argmax of each row's first V columns (evaluation.py:394-399, greedy step) */
+int ns_argmax_rows(const void* logits16, int rows, int V, int ldv, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer tail of one training step on the flat fp32 trainable buffer
+ * (HF Trainer defaults configured at finetune.py:231-253): grad-norm + inf
+ * check -> [skip if inf] unscale, clip to max_grad_norm, AdamW, LR schedule,
+ * GradScaler update; all state on device, no host sync.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay, max_grad_norm;
+  int32_t warmup_steps, total_steps;       /* total_steps <= 0: constant lr */
+  float scale_growth, scale_backoff; int32_t scale_interval;
+} ns_adamw_cfg;
+size_t ns_grad_norm_workspace_bytes(void);
+int ns_grad_norm(const float* g, size_t n, void* workspace, float* norm2_dev, int* found_inf_dev, void* stream);
+int ns_adamw_step(float* p, const float* g, float* m, float* v, size_t n, const ns_adamw_cfg* cfg,
+                  int* step_dev, const float* norm2_dev, const int* found_inf_dev, float* loss_scale_dev,
+                  int* growth_tracker_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUSPEECH_HIP_H */

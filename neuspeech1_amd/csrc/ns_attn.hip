@@ -1,0 +1,456 @@
+// Fused (flash-style) multi-head attention for head_dim 64, fp16 in / fp32 softmax.
+// Replaces HF:modeling_whisper.py:215-238 (eager_attention_forward: QK^T, softmax,
+// PV) and its autograd backward for encoder self-attention (S=1500, no mask),
+// decoder causal self-attention and decoder->encoder cross-attention.
+//
+// Orientation: every product is formed TRANSPOSED so that the softmax row (one
+// query) lives on ONE lane pair (l, l^32) of v_mfma_f32_32x32x16_f16's C/D layout:
+//   S^T[key][q] = K * Q^T      A = K rows from LDS,   B = Q rows in registers
+//   O^T[d][q]  += V^T * P^T    A = V^T from a transposed LDS image, B = the S^T
+//                               accumulator itself (converted to fp16 in place:
+//                               no LDS round trip, no cross-lane traffic)
+// Row max / sum / rescale are therefore per-lane scalars.
+//
+// q is expected PRE-SCALED (head_dim^-0.5 is folded into the q projection, as
+// HF does at modeling_whisper.py:309), so no scale is applied here.
+//
+// Layout: Q/K/V/O/dO are token-major matrices; row (b*L + i), head h at column
+// h*64; row strides are arguments so the fused (q|k|v) projection buffer is
+// consumed in place.
+#include "ns_common.h"
+
+namespace {
+
+constexpr int D = 64;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// ---- staging helpers (256 threads, tile = 64 rows x 64 halfs) ------------------
+// row-major image: thread handles 2 x 16 B
+__device__ __forceinline__ void load_rm(const half_t* __restrict__ base, long long ld, int row0, int L, uint4 r[2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = threadIdx.x + 256 * it;
+    const int row = min(row0 + (id >> 3), L - 1);
+    r[it] = *(const uint4*)(base + (long long)row * ld + (id & 7) * 8);
+  }
+}
+__device__ __forceinline__ void store_rm(char* lds, const uint4 r[2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = threadIdx.x + 256 * it;
+    *(uint4*)(lds + lds_off(id >> 3, id & 7)) = r[it];
+  }
+}
+// transposed image T[col][row-permuted]: chunk g (8 rows) of column c holds rows
+//   16*(g>>1) + 8*(j>>2) + 4*(g&1) + (j&3),  j = 0..7
+// which is the k-order v_mfma_f32_32x32x16 expects when the OTHER operand is a
+// 32x32 accumulator converted in place (cdna guide §3 "accumulator as operand").
+__device__ __forceinline__ void load_tr(const half_t* __restrict__ base, long long ld, int row0, int L, uint32_t w[8]) {
+  const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int rl = 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3);
+    const int row = min(row0 + rl, L - 1);
+    w[j] = *(const uint32_t*)(base + (long long)row * ld + 2 * q);
+  }
+}
+__device__ __forceinline__ void store_tr(char* lds, const uint32_t w[8]) {
+  const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
+  uint4 lo, hi;
+  lo.x = (w[0] & 0xFFFFu) | (w[1] << 16);
+  lo.y = (w[2] & 0xFFFFu) | (w[3] << 16);
+  lo.z = (w[4] & 0xFFFFu) | (w[5] << 16);
+  lo.w = (w[6] & 0xFFFFu) | (w[7] << 16);
+  hi.x = (w[0] >> 16) | (w[1] & 0xFFFF0000u);
+  hi.y = (w[2] >> 16) | (w[3] & 0xFFFF0000u);
+  hi.z = (w[4] >> 16) | (w[5] & 0xFFFF0000u);
+  hi.w = (w[6] >> 16) | (w[7] & 0xFFFF0000u);
+  *(uint4*)(lds + lds_off(2 * q, g)) = lo;
+  *(uint4*)(lds + lds_off(2 * q + 1, g)) = hi;
+}
+
+__device__ __forceinline__ half8 cvt8(const f32x16& x, int base) {
+  half8 h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (half_t)x[base + j];
+  return h;
+}
+// row index inside a 32x32 C/D tile held by register r of this lane
+__device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// =============================================================== forward
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
+  char* const Ks = smem;
+  char* const Vt = smem + 8192;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const int qi = q0 + wave * 32 + lr;           // this lane's query
+  const int qrow = min(qi, p.Lq - 1);
+  const int coff = p.Lk - p.Lq;                   // causal: key j visible iff j <= qi + coff
+
+  half8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(Q + (long long)qrow * p.ldq + 16 * s + 8 * lh);
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int kend = p.Lk;
+  if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);  // keys beyond the block's last query are never visible
+  const int ntiles = (max(kend, 0) + 63) / 64;
+
+  uint4 kr[2];
+  uint32_t vw[8];
+  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr); load_tr(V, p.ldv, 0, p.Lk, vw); }
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * 64;
+    __syncthreads();
+    store_rm(Ks, kr);
+    store_tr(Vt, vw);
+    __syncthreads();
+    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr); load_tr(V, p.ldv, k0 + 64, p.Lk, vw); }
+
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 a = *(const half8*)(Ks + lds_off(kt * 32 + lr, 2 * s + lh));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], st[kt], 0, 0, 0);
+      }
+    }
+    // mask + running max
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kt * 32 + crow(r, lh);
+        bool ok = key < p.Lk;
+        if (CAUSAL) ok = ok && (key <= qi + coff);
+        const float v = ok ? st[kt][r] : -INFINITY;
+        st[kt][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(st[kt][r] - m_use);
+        st[kt][r] = e;
+        ls += e;
+      }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const half8 pb = cvt8(st[kt], 8 * s2);
+        const int sg = kt * 2 + s2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const half8 a = *(const half8*)(Vt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, ot[dt], 0, 0, 0);
+        }
+      }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qi < p.Lq) {
+    half_t* O = (half_t*)p.O + ((long long)b * p.Lq + qi) * p.ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][4 * g + e] * inv);
+        *(half4*)(O + dt * 32 + 8 * g + 4 * lh) = o;
+      }
+    if (p.LSE && lh == 0) p.LSE[((long long)b * p.H + h) * p.Lq + qi] = m_run + __logf(l_tot);
+  }
+}
+
+// =============================================================== backward: dQ (+ delta)
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * 8192];
+  char* const Ks = smem;
+  char* const Kt = smem + 8192;
+  char* const Vs = smem + 16384;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const half_t* O = (const half_t*)p.O + (long long)b * p.Lq * p.ldo + h * D;
+  const half_t* dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
+  const int qi = q0 + wave * 32 + lr;
+  const int qrow = min(qi, p.Lq - 1);
+  const int coff = p.Lk - p.Lq;
+
+  half8 qf[4], dof[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *(const half8*)(Q + (long long)qrow * p.ldq + 16 * s + 8 * lh);
+    dof[s] = *(const half8*)(dO + (long long)qrow * p.lddo + 16 * s + 8 * lh);
+    const half8 of = *(const half8*)(O + (long long)qrow * p.ldo + 16 * s + 8 * lh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
+  }
+  const float delta = dl + __shfl_xor(dl, 32, 64);
+  const long long stat = ((long long)b * p.H + h) * p.Lq + qrow;
+  const float lse = p.LSE[stat];
+  if (qi < p.Lq && lh == 0) p.Delta[stat] = delta;
+
+  f32x16 dqt[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[t][r] = 0.f;
+
+  int kend = p.Lk;
+  if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);
+  const int ntiles = (max(kend, 0) + 63) / 64;
+
+  uint4 kr[2], vr[2];
+  uint32_t kw[8];
+  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr); load_rm(V, p.ldv, 0, p.Lk, vr); load_tr(K, p.ldk, 0, p.Lk, kw); }
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * 64;
+    __syncthreads();
+    store_rm(Ks, kr); store_rm(Vs, vr); store_tr(Kt, kw);
+    __syncthreads();
+    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr); load_rm(V, p.ldv, k0 + 64, p.Lk, vr); load_tr(K, p.ldk, k0 + 64, p.Lk, kw); }
+
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[kt][r] = 0.f; dp[kt][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 ak = *(const half8*)(Ks + lds_off(kt * 32 + lr, 2 * s + lh));
+        const half8 av = *(const half8*)(Vs + lds_off(kt * 32 + lr, 2 * s + lh));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, qf[s], st[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, dof[s], dp[kt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kt * 32 + crow(r, lh);
+        bool ok = key < p.Lk;
+        if (CAUSAL) ok = ok && (key <= qi + coff);
+        const float pv = ok ? __expf(st[kt][r] - lse) : 0.f;
+        st[kt][r] = pv * (dp[kt][r] - delta);  // dS^T
+      }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const half8 dsb = cvt8(st[kt], 8 * s2);
+        const int sg = kt * 2 + s2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const half8 a = *(const half8*)(Kt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, dsb, dqt[dt], 0, 0, 0);
+        }
+      }
+  }
+  if (qi < p.Lq) {
+    half_t* dQ = (half_t*)p.dQ + ((long long)b * p.Lq + qi) * p.lddq + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)dqt[dt][4 * g + e];
+        *(half4*)(dQ + dt * 32 + 8 * g + 4 * lh) = o;
+      }
+  }
+}
+
+// =============================================================== backward: dK, dV
+// One wave owns 32 keys (on the lanes); the block sweeps 64-query tiles.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
+  char* const Qs = smem;
+  char* const Qt = smem + 8192;
+  char* const dOs = smem + 16384;
+  char* const dOt = smem + 24576;
+  float* const lse_s = (float*)(smem + 32768);
+  float* const del_s = lse_s + 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;
+  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const half_t* dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
+  const float* LSE = p.LSE + ((long long)b * p.H + h) * p.Lq;
+  const float* Delta = p.Delta + ((long long)b * p.H + h) * p.Lq;
+  const int key = kb0 + wave * 32 + lr;
+  const int krow = min(key, p.Lk - 1);
+  const int coff = p.Lk - p.Lq;
+
+  half8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
+    vf[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
+  }
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[t][r] = 0.f; dvt[t][r] = 0.f; }
+
+  int qstart = 0;
+  if (CAUSAL) qstart = max(0, kb0 - coff) / 64 * 64;  // queries before the block's first key see none of its keys
+  const int ntiles = (p.Lq - qstart + 63) / 64;
+
+  uint4 qr[2], dr[2];
+  uint32_t qw[8], dw[8];
+  float lse_r = 0.f, del_r = 0.f;
+  auto load_all = [&](int q0) {
+    load_rm(Q, p.ldq, q0, p.Lq, qr); load_rm(dO, p.lddo, q0, p.Lq, dr);
+    load_tr(Q, p.ldq, q0, p.Lq, qw); load_tr(dO, p.lddo, q0, p.Lq, dw);
+    if (threadIdx.x < 64) { const int qq = min(q0 + (int)threadIdx.x, p.Lq - 1); lse_r = LSE[qq]; del_r = Delta[qq]; }
+  };
+  if (ntiles > 0) load_all(qstart);
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = qstart + t * 64;
+    __syncthreads();
+    store_rm(Qs, qr); store_rm(dOs, dr); store_tr(Qt, qw); store_tr(dOt, dw);
+    if (threadIdx.x < 64) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
+    __syncthreads();
+    if (t + 1 < ntiles) load_all(q0 + 64);
+
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[qt][r] = 0.f; dp[qt][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 aq = *(const half8*)(Qs + lds_off(qt * 32 + lr, 2 * s + lh));
+        const half8 ad = *(const half8*)(dOs + lds_off(qt * 32 + lr, 2 * s + lh));
+        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, kf[s], st[qt], 0, 0, 0);   // S[q][key]
+        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, vf[s], dp[qt], 0, 0, 0);   // dP[q][key]
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qt * 32 + crow(r, lh);
+        const int qi = q0 + ql;
+        bool ok = (qi < p.Lq) && (key < p.Lk);
+        if (CAUSAL) ok = ok && (key <= qi + coff);
+        const float pv = ok ? __expf(st[qt][r] - lse_s[ql]) : 0.f;
+        st[qt][r] = pv;                              // P
+        dp[qt][r] = pv * (dp[qt][r] - del_s[ql]);    // dS
+      }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const half8 pb = cvt8(st[qt], 8 * s2);
+        const half8 dsb = cvt8(dp[qt], 8 * s2);
+        const int sg = qt * 2 + s2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const half8 a1 = *(const half8*)(dOt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          const half8 a2 = *(const half8*)(Qt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, dsb, dkt[dt], 0, 0, 0);
+        }
+      }
+  }
+  if (key < p.Lk) {
+    half_t* dK = (half_t*)p.dK + ((long long)b * p.Lk + key) * p.lddk + h * D;
+    half_t* dV = (half_t*)p.dV + ((long long)b * p.Lk + key) * p.lddv + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 ok_, ov_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ok_[e] = (half_t)dkt[dt][4 * g + e]; ov_[e] = (half_t)dvt[dt][4 * g + e]; }
+        *(half4*)(dK + dt * 32 + 8 * g + 4 * lh) = ok_;
+        *(half4*)(dV + dt * 32 + 8 * g + 4 * lh) = ov_;
+      }
+  }
+}
+
+int check_desc(const ns_attn_desc* d, bool bwd) {
+  NS_CHECK_ARG(d, "ns_attn: null descriptor");
+  NS_CHECK_ARG(d->head_dim == 64, "ns_attn: head_dim=%d unsupported (only 64)", d->head_dim);
+  NS_CHECK_ARG(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0, "ns_attn: bad shape");
+  NS_CHECK_ARG(d->Q && d->K && d->V && d->O, "ns_attn: null tensor");
+  NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0, "ns_attn: row strides must be multiples of 8");
+  if (bwd) {
+    NS_CHECK_ARG(d->dO && d->dQ && d->dK && d->dV && d->LSE && d->Delta, "ns_attn_bwd: null tensor");
+    NS_CHECK_ARG(d->lddo % 8 == 0 && d->lddq % 8 == 0 && d->lddk % 8 == 0 && d->lddv % 8 == 0, "ns_attn_bwd: row strides must be multiples of 8");
+  }
+  return NS_OK;
+}
+
+}  // namespace
+
+extern "C" int ns_attn_fwd(const ns_attn_desc* d, void* stream) {
+  int rc = check_desc(d, false);
+  if (rc) return rc;
+  dim3 grid((d->Lq + 127) / 128, d->H, d->B);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, st, *d);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, st, *d);
+  NS_CHECK_LAUNCH("ns_attn_fwd");
+  return NS_OK;
+}
+
+extern "C" int ns_attn_bwd(const ns_attn_desc* d, void* stream) {
+  int rc = check_desc(d, true);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gq((d->Lq + 127) / 128, d->H, d->B), gk((d->Lk + 127) / 128, d->H, d->B);
+  if (d->causal) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, st, *d);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(256), 0, st, *d);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), 0, st, *d);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(256), 0, st, *d);
+  }
+  NS_CHECK_LAUNCH("ns_attn_bwd");
+  return NS_OK;
+}

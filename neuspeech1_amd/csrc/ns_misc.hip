@@ -1,0 +1,194 @@
+// Byte-moving kernels of the path: MEG signal pack, token embedding, operand
+// refresh (cast / transpose jobs), plus the ABI bookkeeping entry points.
+#include "ns_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void ns_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int ns_version(void) { return 1; }
+extern "C" const char* ns_last_error(void) { return g_err; }
+
+namespace {
+
+// (B, ch, T) fp32 channel-major  ->  (B, T+2, Cp) fp16 token-major with a zero
+// halo row at both ends and zero channel padding.  Reads are coalesced along T
+// (256 B per wave-instruction), writes are 16 B per lane along the channel axis.
+// Block = 256 threads handles 64 time steps x 64 channels through an LDS tile.
+__global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restrict__ x, half_t* __restrict__ out, int ch,
+                                                           int T, int Cp) {
+  __shared__ half_t tile[64][66];  // [channel][time], +2 pad
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* xb = x + (size_t)b * ch * T;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + w * 16 + i, t = t0 + lane;
+    float v = 0.f;
+    if (c < ch && t < T) v = xb[(size_t)c * T + t];
+    tile[w * 16 + i][lane] = (half_t)v;
+  }
+  __syncthreads();
+  half_t* ob = out + (size_t)b * (T + 2) * Cp;
+  const int cc = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int tl = (threadIdx.x >> 3) + 32 * it;
+    const int t = t0 + tl;
+    if (t < T) {
+      half8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = tile[cc + e][tl];
+      *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = h;
+    }
+  }
+  // halo rows
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    ob[c0 + threadIdx.x] = (half_t)0.f;
+    ob[(size_t)(T + 1) * Cp + c0 + threadIdx.x] = (half_t)0.f;
+  }
+}
+
+// h32[row] = E32[id[row]] + P32[pos0 + (row % L)]   (utils/load_model.py:645,668-673)
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E,
+                                                     const float* __restrict__ P, float* __restrict__ h, int rows, int L,
+                                                     int d, int pos0, const int* __restrict__ pos0_dev) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t id = ids[row];
+  const int p0 = pos0_dev ? *pos0_dev : pos0;
+  const float* e = E + (size_t)id * d;
+  const float* p = P + (size_t)(p0 + row % L) * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 a = *(const float4*)(e + c);
+    const float4 b = *(const float4*)(p + c);
+    *(float4*)(h + (size_t)row * d + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// batched operand refresh: dst16[r][c] = scale * src32[...]; transpose optional
+__global__ __launch_bounds__(256) void cast_jobs_kernel(const ns_cast_job* __restrict__ jobs) {
+  const ns_cast_job j = jobs[blockIdx.y];
+  __shared__ float tile[32][33];
+  const int tiles_c = (j.cols + 31) / 32;
+  const int tiles_r = (j.rows + 31) / 32;
+  const float* src = (const float*)j.src;
+  half_t* dst = (half_t*)j.dst;
+  for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    if (!j.transpose) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < j.rows && c < j.cols) dst[(size_t)r * j.ld_dst + c] = (half_t)(j.scale * src[(size_t)r * j.ld_src + c]);
+      }
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < j.rows && c < j.cols) ? src[(size_t)r * j.ld_src + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;  // dst is (cols x rows)
+        if (r < j.rows && c < j.cols) dst[(size_t)c * j.ld_dst + r] = (half_t)(j.scale * tile[tx][ty + 8 * i]);
+      }
+    }
+  }
+}
+
+
+// out16[map(row)][c] = round16(a16[row][c] * gelu'(pre16[row][c]))   (conv-stem backward seam)
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const half_t* __restrict__ a, const half_t* __restrict__ pre,
+                                                         half_t* __restrict__ out, ns_rowmap om, int rows, int cols) {
+  const int cpr = cols / 8;
+  const long long total = (long long)rows * cpr;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / cpr), c = (int)(i - (long long)row * cpr) * 8;
+    const half8 av = *(const half8*)(a + (long long)row * cols + c);
+    const half8 pv = *(const half8*)(pre + (long long)row * cols + c);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)av[e] * ns_gelu_grad((float)pv[e]));
+    long long off;
+    if (om.seg_rows > 0) { const int sg = row / om.seg_rows; off = (long long)sg * om.seg_stride + (long long)(row - sg * om.seg_rows) * om.ld; }
+    else off = (long long)row * om.ld;
+    *(half8*)(out + off + c) = o;
+  }
+}
+
+// out32[c] += alpha * sum_rows a16[row][c]  (bias gradients); 256 rows per block
+__global__ __launch_bounds__(256) void colsum_kernel(const half_t* __restrict__ a, float* __restrict__ out, int rows,
+                                                      int cols, int ld, float alpha) {
+  const int r0 = blockIdx.x * 256, r1 = min(rows, r0 + 256);
+  for (int c = threadIdx.x * 2; c < cols; c += 512) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const half2v v = *(const half2v*)(a + (long long)r * ld + c);
+      s0 += (float)v[0]; s1 += (float)v[1];
+    }
+    atomicAdd(out + c, s0 * alpha);
+    atomicAdd(out + c + 1, s1 * alpha);
+  }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream) {
+  NS_CHECK_ARG(x && out16, "ns_signal_pack: null pointer");
+  NS_CHECK_ARG(B > 0 && ch > 0 && T > 0 && Cp >= ch && Cp % 64 == 0, "ns_signal_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
+  dim3 grid((T + 63) / 64, Cp / 64, B);
+  hipLaunchKernelGGL(signal_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
+  NS_CHECK_LAUNCH("ns_signal_pack");
+  return NS_OK;
+}
+
+extern "C" int ns_embed_pos(const int64_t* ids, const float* E32, const float* P32, float* h32, int rows, int L, int d,
+                            int pos0, const int* pos0_dev, void* stream) {
+  NS_CHECK_ARG(ids && E32 && P32 && h32, "ns_embed_pos: null pointer");
+  NS_CHECK_ARG(rows > 0 && L > 0 && d % 4 == 0, "ns_embed_pos: bad shape");
+  hipLaunchKernelGGL(embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, E32, P32, h32, rows, L,
+                     d, pos0, pos0_dev);
+  NS_CHECK_LAUNCH("ns_embed_pos");
+  return NS_OK;
+}
+
+extern "C" int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream) {
+  NS_CHECK_ARG(jobs_dev && njobs > 0, "ns_cast_jobs: bad arguments");
+  hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  NS_CHECK_LAUNCH("ns_cast_jobs");
+  return NS_OK;
+}
+
+extern "C" int ns_dgelu_mul(const void* a16, const void* pre16, void* out16, const ns_rowmap* out_map, int rows, int cols,
+                            void* stream) {
+  NS_CHECK_ARG(a16 && pre16 && out16 && out_map && rows > 0 && cols > 0 && cols % 8 == 0 && out_map->ld % 8 == 0,
+               "ns_dgelu_mul: bad arguments");
+  long long total = (long long)rows * (cols / 8);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)a16,
+                     (const half_t*)pre16, (half_t*)out16, *out_map, rows, cols);
+  NS_CHECK_LAUNCH("ns_dgelu_mul");
+  return NS_OK;
+}
+
+extern "C" int ns_colsum(const void* a16, float* out32, int rows, int cols, int ld, float alpha, void* stream) {
+  NS_CHECK_ARG(a16 && out32 && rows > 0 && cols > 0 && cols % 2 == 0 && ld % 2 == 0, "ns_colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const half_t*)a16,
+                     out32, rows, cols, ld, alpha);
+  NS_CHECK_LAUNCH("ns_colsum");
+  return NS_OK;
+}

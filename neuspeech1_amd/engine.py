@@ -1,0 +1,728 @@
+"""The MI355X Whisper-MEG engine: explicit forward / backward / optimizer step of
+NeuSpeech's training hot path as a fixed sequence of HIP kernel launches.
+
+There is no autograd graph and no tracing compiler: the model is one known
+architecture, so the backward pass is written out by hand against saved
+activations, which lets gradients land directly in ONE flat fp32 buffer (what
+RCCL all-reduces) in backward-completion order.
+
+Reference path being replaced (file:line in the reference tree / HF):
+  conv stem      utils/model_utils.py:9-23, utils/load_model.py:410-417
+  encoder layer  HF:modeling_whisper.py:360-413 (+ :241-357 attention)
+  decoder layer  HF:modeling_whisper.py:416-506
+  LM head + CE   utils/load_model.py:1025-1054
+  LoRA           finetune.py:187-212 (peft LoraConfig r=32, alpha=64, dropout .05)
+  train step     finetune.py:231-253 (HF Trainer: fp16 autocast + GradScaler,
+                 AdamW, clip 1.0, linear warmup/decay)
+
+Numerics contract: fp32 residual stream, fp32 LayerNorm
+/ softmax / CE statistics, fp16 GEMM operands with fp32 accumulation, fp16
+rounding at every Linear/Conv output, exact-erf GELU evaluated on fp16 values.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from .lib import AdamWCfg
+from .ops import NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_TN, rowmap
+from .weights import LORA_SUFFIXES, WhisperDims
+
+F16, F32 = torch.float16, torch.float32
+
+
+@dataclass
+class LoraSpec:
+    r: int = 32
+    alpha: float = 64.0
+    dropout: float = 0.05
+
+    @property
+    def scale(self) -> float:
+        return self.alpha / self.r
+
+
+@dataclass
+class TrainCfg:
+    lr: float = 1e-3
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    weight_decay: float = 0.0
+    max_grad_norm: float = 1.0
+    warmup_steps: int = 0
+    total_steps: int = 0
+    fp16_scaler: bool = True          # GradScaler semantics (finetune.py:242)
+    init_scale: float = 65536.0
+    growth_factor: float = 2.0
+    backoff_factor: float = 0.5
+    growth_interval: int = 2000
+
+
+class _Lin:
+    """fp16 operand pack of a frozen Linear: W (N,K) for forward, W^T (K,N) for dgrad."""
+    __slots__ = ("w", "wt", "bias", "N", "K")
+
+    def __init__(self, w32: torch.Tensor, b32, scale_rows=None):
+        w = w32.float()
+        b = None if b32 is None else b32.float().clone()
+        if scale_rows is not None:
+            n, s = scale_rows
+            w = w.clone()
+            w[:n] *= s
+            if b is not None:
+                b[:n] *= s
+        self.N, self.K = w.shape
+        self.w = w.to(F16).contiguous()
+        self.wt = w.t().to(F16).contiguous()
+        self.bias = b
+
+
+class MegWhisperEngine:
+    def __init__(self, dims: WhisperDims, sd: dict, lora: LoraSpec | None = None, lora_sd: dict | None = None,
+                 train_cfg: TrainCfg | None = None, device="cuda:0", train_convs: bool = True):
+        self.dims, self.dev = dims, torch.device(device)
+        self.lora = lora
+        self.tc = train_cfg or TrainCfg()
+        self.train_convs = train_convs
+        d = dims.d
+        assert d % 256 == 0 and d // dims.heads == 64, "kernels need d % 256 == 0 and head_dim 64"
+        assert dims.src_pos % 4 == 0 and dims.src_pos >= 64
+        g = lambda k: torch.as_tensor(sd[k]).to(self.dev, F32)  # noqa: E731
+        self._sd_get = g
+        s = 64 ** -0.5
+        self.r = lora.r if lora else 0
+        assert self.r % 16 == 0
+        # ---------------- frozen operand packs
+        e = "model.encoder."
+        self.enc_pos = g(e + "embed_positions.weight").contiguous()
+        self.enc = []
+        for i in range(dims.enc_layers):
+            p = f"{e}layers.{i}."
+            zk = torch.zeros(d, device=self.dev)
+            L = {}
+            L["qkv"] = _Lin(torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                       g(p + "self_attn.v_proj.weight")], 0),
+                            torch.cat([g(p + "self_attn.q_proj.bias"), zk, g(p + "self_attn.v_proj.bias")], 0), (d, s))
+            L["out"] = _Lin(g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
+            L["fc1"] = _Lin(g(p + "fc1.weight"), g(p + "fc1.bias"))
+            L["fc2"] = _Lin(g(p + "fc2.weight"), g(p + "fc2.bias"))
+            L["ln1"] = (g(p + "self_attn_layer_norm.weight"), g(p + "self_attn_layer_norm.bias"))
+            L["ln2"] = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+            self.enc.append(L)
+        self.enc_ln = (g(e + "layer_norm.weight"), g(e + "layer_norm.bias"))
+        dd = "model.decoder."
+        self.E32 = g(dd + "embed_tokens.weight").contiguous()
+        self.dec_pos = g(dd + "embed_positions.weight").contiguous()
+        Ep = torch.zeros(dims.vocab_pad, d, device=self.dev, dtype=F16)
+        Ep[:dims.vocab] = self.E32.to(F16)
+        self.E16 = Ep
+        self.E16T = Ep.t().contiguous()
+        self.dec = []
+        for i in range(dims.dec_layers):
+            p = f"{dd}layers.{i}."
+            zk = torch.zeros(d, device=self.dev)
+            L = {}
+            L["qkv"] = _Lin(torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                       g(p + "self_attn.v_proj.weight")], 0),
+                            torch.cat([g(p + "self_attn.q_proj.bias"), zk, g(p + "self_attn.v_proj.bias")], 0), (d, s))
+            L["out"] = _Lin(g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
+            L["cq"] = _Lin(g(p + "encoder_attn.q_proj.weight"), g(p + "encoder_attn.q_proj.bias"), (d, s))
+            L["ckv"] = _Lin(torch.cat([g(p + "encoder_attn.k_proj.weight"), g(p + "encoder_attn.v_proj.weight")], 0),
+                            torch.cat([zk, g(p + "encoder_attn.v_proj.bias")], 0))
+            L["cout"] = _Lin(g(p + "encoder_attn.out_proj.weight"), g(p + "encoder_attn.out_proj.bias"))
+            L["fc1"] = _Lin(g(p + "fc1.weight"), g(p + "fc1.bias"))
+            L["fc2"] = _Lin(g(p + "fc2.weight"), g(p + "fc2.bias"))
+            L["ln1"] = (g(p + "self_attn_layer_norm.weight"), g(p + "self_attn_layer_norm.bias"))
+            L["ln2"] = (g(p + "encoder_attn_layer_norm.weight"), g(p + "encoder_attn_layer_norm.bias"))
+            L["ln3"] = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+            self.dec.append(L)
+        self.dec_ln = (g(dd + "layer_norm.weight"), g(dd + "layer_norm.bias"))
+        self._build_trainables(sd, lora_sd)
+        self._bufs = {}
+        self._init_opt_state()
+
+    # ------------------------------------------------------------------ trainables
+    def _build_trainables(self, sd, lora_sd):
+        """One flat fp32 buffer, ordered by backward completion: LoRA of the top encoder layer first, conv stem last."""
+        dims, d, f, r = self.dims, self.dims.d, self.dims.ffn, self.r
+        Cp = dims.ch_pad
+        segs = []  # (name, numel)
+        self.lora_names = []
+        if self.lora:
+            for i in reversed(range(dims.enc_layers)):
+                p = f"model.encoder.layers.{i}."
+                # A of q,k,v contiguous -> one stacked (3r, d) operand
+                segs += [(p + "self_attn.qkv.lora_A", 3 * r * d)]
+                for nm in ("q_proj", "k_proj", "v_proj"):
+                    segs.append((p + f"self_attn.{nm}.lora_B", d * r))
+                segs += [(p + "self_attn.out_proj.lora_A", r * d), (p + "self_attn.out_proj.lora_B", d * r),
+                         (p + "fc1.lora_A", r * d), (p + "fc1.lora_B", f * r),
+                         (p + "fc2.lora_A", r * f), (p + "fc2.lora_B", d * r)]
+        segs += [("model.encoder.conv2.wp", d * 3 * d), ("model.encoder.conv2.bias", d),
+                 ("model.encoder.conv1.2.wp", d * 3 * d), ("model.encoder.conv1.2.bias", d),
+                 ("model.encoder.conv1.0.wp", d * 3 * Cp), ("model.encoder.conv1.0.bias", d)]
+        self.seg_off = {}
+        off = 0
+        for nm, n in segs:
+            self.seg_off[nm] = (off, n)
+            off += (n + 63) // 64 * 64
+        self.n_train = off
+        self.P = torch.zeros(off, device=self.dev, dtype=F32)
+        self.G = torch.zeros(off, device=self.dev, dtype=F32)
+        self.lora_end = self.seg_off["model.encoder.conv2.wp"][0]
+        g = self._sd_get
+        # conv masters in packed GEMM layout (N, 3, Cp): wp[n, k, c] = w[n, c, k]
+        for nm, cin, cp in (("conv2", d, d), ("conv1.2", d, d), ("conv1.0", dims.ch, Cp)):
+            w = g(f"model.encoder.{nm}.weight")
+            wp = self.pview(f"model.encoder.{nm}.wp").view(d, 3, cp)
+            wp[:, :, :cin] = w.permute(0, 2, 1)
+            self.pview(f"model.encoder.{nm}.bias").copy_(g(f"model.encoder.{nm}.bias"))
+        if self.lora:
+            for i in range(dims.enc_layers):
+                p = f"model.encoder.layers.{i}."
+                A = self.pview(p + "self_attn.qkv.lora_A").view(3, r, d)
+                for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                    if lora_sd is not None:
+                        A[j].copy_(torch.as_tensor(lora_sd[p + f"self_attn.{nm}.lora_A.weight"]))
+                        self.pview(p + f"self_attn.{nm}.lora_B").view(d, r).copy_(
+                            torch.as_tensor(lora_sd[p + f"self_attn.{nm}.lora_B.weight"]))
+                    else:
+                        torch.nn.init.kaiming_uniform_(A[j], a=math.sqrt(5))
+                for nm, (no, ki) in (("self_attn.out_proj", (d, d)), ("fc1", (f, d)), ("fc2", (d, f))):
+                    a = self.pview(p + nm + ".lora_A").view(r, ki)
+                    if lora_sd is not None:
+                        a.copy_(torch.as_tensor(lora_sd[p + nm + ".lora_A.weight"]))
+                        self.pview(p + nm + ".lora_B").view(no, r).copy_(torch.as_tensor(lora_sd[p + nm + ".lora_B.weight"]))
+                    else:
+                        torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+        self._build_operand_copies()
+
+    def pview(self, name):
+        o, n = self.seg_off[name]
+        return self.P[o:o + n]
+
+    def gview(self, name):
+        o, n = self.seg_off[name]
+        return self.G[o:o + n]
+
+    def _build_operand_copies(self):
+        """fp16 operand copies of the trainables + the device job table that refreshes them after each step."""
+        dims, d, f, r = self.dims, self.dims.d, self.dims.ffn, self.r
+        Cp = dims.ch_pad
+        jobs = []
+        z = lambda *s: torch.zeros(*s, device=self.dev, dtype=F16)  # noqa: E731
+        P = self.P
+        pp = lambda name: P.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
+        self.conv_ops = {}
+        for nm, cp in (("conv2", d), ("conv1.2", d), ("conv1.0", Cp)):
+            key = f"model.encoder.{nm}"
+            o = {"w": z(d, 3 * cp), "cp": cp}
+            jobs.append((pp(key + ".wp"), o["w"].data_ptr(), d, 3 * cp, 3 * cp, 3 * cp, 1.0, 0))
+            if nm != "conv1.0":  # stride-2 dgrad operands: even rows use tap 1, odd rows taps (2 | 0)
+                o["we"] = z(cp, d)
+                o["wo"] = z(cp, 2 * d)
+                jobs.append((pp(key + ".wp") + 4 * cp, o["we"].data_ptr(), d, cp, 3 * cp, d, 1.0, 1))
+                jobs.append((pp(key + ".wp") + 4 * 2 * cp, o["wo"].data_ptr(), d, cp, 3 * cp, 2 * d, 1.0, 1))
+                jobs.append((pp(key + ".wp"), o["wo"].data_ptr() + 2 * d, d, cp, 3 * cp, 2 * d, 1.0, 1))
+            self.conv_ops[nm] = o
+        self.lora_ops = []
+        if self.lora:
+            sc = self.lora.scale
+            qs = 64 ** -0.5
+            for i in range(dims.enc_layers):
+                p = f"model.encoder.layers.{i}."
+                o = {"Aqkv": z(3 * r, d), "AqkvT": z(d, 3 * r), "sBqkv": z(3 * d, r),
+                     "sBqT": z(r, d), "sBkT": z(r, d), "sBvT": z(r, d)}
+                jobs.append((pp(p + "self_attn.qkv.lora_A"), o["Aqkv"].data_ptr(), 3 * r, d, d, d, 1.0, 0))
+                jobs.append((pp(p + "self_attn.qkv.lora_A"), o["AqkvT"].data_ptr(), 3 * r, d, d, 3 * r, 1.0, 1))
+                for j, (nm, s_) in enumerate((("q_proj", sc * qs), ("k_proj", sc), ("v_proj", sc))):
+                    src = pp(p + f"self_attn.{nm}.lora_B")
+                    jobs.append((src, o["sBqkv"].data_ptr() + 2 * j * d * r, d, r, r, r, s_, 0))
+                    jobs.append((src, o[("sBqT", "sBkT", "sBvT")[j]].data_ptr(), d, r, r, d, s_, 1))
+                for nm, key, no, ki in (("self_attn.out_proj", "out", d, d), ("fc1", "fc1", f, d), ("fc2", "fc2", d, f)):
+                    o[key + "_A"] = z(r, ki)
+                    o[key + "_AT"] = z(ki, r)
+                    o[key + "_sB"] = z(no, r)
+                    o[key + "_sBT"] = z(r, no)
+                    jobs.append((pp(p + nm + ".lora_A"), o[key + "_A"].data_ptr(), r, ki, ki, ki, 1.0, 0))
+                    jobs.append((pp(p + nm + ".lora_A"), o[key + "_AT"].data_ptr(), r, ki, ki, r, 1.0, 1))
+                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sB"].data_ptr(), no, r, r, r, sc, 0))
+                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sBT"].data_ptr(), no, r, r, no, sc, 1))
+                self.lora_ops.append(o)
+        self._job_table, self._njobs = ops.make_cast_jobs(jobs, self.dev)
+        self.refresh_operands()
+
+    def refresh_operands(self):
+        ops.cast_jobs(self._job_table, self._njobs)
+
+    def _init_opt_state(self):
+        n, dev = self.n_train, self.dev
+        self.M1 = torch.zeros(n, device=dev)
+        self.M2 = torch.zeros(n, device=dev)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.norm2_dev = torch.zeros(1, device=dev)
+        self.found_inf_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.loss_scale_dev = torch.tensor([self.tc.init_scale if self.tc.fp16_scaler else 1.0], device=dev)
+        self.growth_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.norm_ws = torch.empty(8192, device=dev, dtype=torch.uint8)
+        self.loss_dev = torch.zeros(1, device=dev)
+        self.nvalid_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.drop_seed = 0x1234
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, B: int, L: int, train: bool):
+        key = (B, L, train)
+        if key in self._bufs:
+            return self._bufs[key]
+        dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
+        T, S, Cp = dims.T, dims.src_pos, dims.ch_pad
+        M, ML = B * S, B * L
+        dev = self.dev
+        h16 = lambda *s: torch.zeros(*s, device=dev, dtype=F16)  # noqa: E731  (zeros: halo rows must be 0)
+        f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
+        b = {"B": B, "L": L}
+        b["xin"] = h16(B, T + 2, Cp)
+        b["pre0"] = h16(B * T, d)
+        b["g0"] = h16(B, T + 2, d)
+        b["pre1"] = h16(B * T // 2, d)
+        b["g1"] = h16(B, T // 2 + 2, d)
+        b["pre2"] = h16(M, d)
+        ne = dims.enc_layers
+        b["h"] = [f32(M, d) for _ in range((2 * ne + 1) if train else 2)]
+        nl = ne if train else 1
+        b["x1"] = [h16(M, d) for _ in range(nl)]
+        b["x2"] = [h16(M, d) for _ in range(nl)]
+        b["st1"] = [(f32(M), f32(M)) for _ in range(nl)]
+        b["st2"] = [(f32(M), f32(M)) for _ in range(nl)]
+        b["qkv"] = [h16(M, 3 * d) for _ in range(nl)]
+        b["ao"] = [h16(M, d) for _ in range(nl)]
+        b["lse"] = [f32(B, H, S) for _ in range(nl)]
+        b["pre_f"] = [h16(M, f) for _ in range(nl)]
+        b["gf"] = [h16(M, f) for _ in range(nl)]
+        if r:
+            b["uqkv"] = [h16(M, 3 * r) for _ in range(nl)]
+            b["uo"] = [h16(M, r) for _ in range(nl)]
+            b["u1"] = [h16(M, r) for _ in range(nl)]
+            b["u2"] = [h16(M, r) for _ in range(nl)]
+        b["enc16"] = h16(M, d)
+        b["enc_st"] = (f32(M), f32(M))
+        nd = dims.dec_layers
+        ndl = nd if train else 1
+        if L > 0:
+            b["hd"] = [f32(ML, d) for _ in range((3 * nd + 1) if train else 2)]
+            for k in ("xs", "xc", "xm", "ao_s", "ao_c", "q_c"):
+                b[k] = [h16(ML, d) for _ in range(ndl)]
+            for k in ("st_s", "st_c", "st_m"):
+                b[k] = [(f32(ML), f32(ML)) for _ in range(ndl)]
+            b["qkv_s"] = [h16(ML, 3 * d) for _ in range(ndl)]
+            b["kv_c"] = [h16(M, 2 * d) for _ in range(ndl)]
+            b["lse_s"] = [f32(B, H, L) for _ in range(ndl)]
+            b["lse_c"] = [f32(B, H, L) for _ in range(ndl)]
+            b["pre_fd"] = [h16(ML, f) for _ in range(ndl)]
+            b["gfd"] = [h16(ML, f) for _ in range(ndl)]
+            b["xd"] = h16(ML, d)
+            b["st_d"] = (f32(ML), f32(ML))
+            b["logits"] = h16(ML, dims.vocab_pad)
+            b["row_loss"] = f32(ML)
+            b["dec_ids"] = torch.zeros(B, L, device=dev, dtype=torch.int64)
+        if train:
+            b["dh32"] = f32(M, d)
+            b["dh16"] = h16(M, d)
+            b["dx16"] = h16(M, d)
+            b["dqkv"] = h16(M, 3 * d)
+            b["dpre_f"] = h16(M, f)
+            b["dao"] = h16(M, d)
+            b["delta"] = f32(B, H, S)
+            b["denc32"] = f32(M, d)
+            b["dkv_c"] = h16(M, 2 * d)
+            if r:
+                b["du3"] = h16(M, 3 * r)
+                b["du"] = h16(M, r)
+            b["ddh32"] = f32(ML, d)
+            b["ddh16"] = h16(ML, d)
+            b["ddx16"] = h16(ML, d)
+            b["ddqkv"] = h16(ML, 3 * d)
+            b["ddq_c"] = h16(ML, d)
+            b["ddao"] = h16(ML, d)
+            b["ddpre_f"] = h16(ML, f)
+            b["ddelta"] = f32(B, H, L)
+            b["dpre2"] = h16(B, S + 2, d)
+            b["dg1"] = h16(B * T // 2, d)
+            b["dpre1"] = h16(B, T // 2 + 2, d)
+            b["dg0"] = h16(B * T, d)
+            b["dpre0"] = h16(B * T, d)
+        self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------ helpers
+    def _lin(self, x16, M, lin: _Lin, *, C16=None, ldc=None, G16=None, R32=None, H32=None, gelu=False,
+             A2=None, lda2=0, K2=0, B2=None, ngroup=0):
+        ops.gemm(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias,
+                 A2=A2, am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
+                 a2_ngroup=ngroup,
+                 C16=C16, c16m=rowmap(ldc or lin.N) if C16 is not None else None,
+                 G16=G16, g16m=rowmap(lin.N) if G16 is not None else None,
+                 R32=R32, H32=H32, h32m=rowmap(lin.N) if H32 is not None else None,
+                 flags=NS_GEMM_GELU if gelu else 0)
+
+    def _dgrad(self, dy16, M, lin: _Lin, out16, *, ldy=None, P16=None, A2=None, lda2=0, K2=0, B2=None,
+               R32=None, H32=None, drop=False):
+        """dx = dy * W  (+ du * A for LoRA), optional gelu' epilogue or fp32 accumulate."""
+        ops.gemm(A=dy16, am=rowmap(ldy or lin.N), K=lin.N, B=lin.wt, ldb=lin.N, M=M, N=lin.K,
+                 A2=A2, am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
+                 C16=out16, c16m=rowmap(lin.K) if out16 is not None else None,
+                 P16=P16, p16m=rowmap(lin.K) if P16 is not None else None,
+                 R32=R32, H32=H32, h32m=rowmap(lin.K) if H32 is not None else None,
+                 flags=NS_GEMM_DGELU if P16 is not None else 0,
+                 drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
+
+    def _drop_p(self):
+        return self.lora.dropout if (self.lora and self.training_mode) else 0.0
+
+    def _wgrad(self, dy16, ldy, x16, ldx, Mred, No, Ko, gname, alpha=1.0, goff=0, ldc=None, drop=False,
+               am=None, bm=None):
+        gptr = self.G.data_ptr() + 4 * (self.seg_off[gname][0] + goff)
+        tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
+        splits = max(1, min(Mred // 256, (768 + tiles - 1) // tiles))
+        ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
+                 ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=splits, alpha=alpha,
+                 drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, x32: torch.Tensor, b: dict, train: bool):
+        """MEG signal (B, ch, T) fp32 -> encoder states enc16 (B*S, d) fp16."""
+        dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
+        B, T, S, Cp = b["B"], dims.T, dims.src_pos, dims.ch_pad
+        M = B * S
+        assert x32.shape == (B, dims.ch, T) and x32.dtype == F32 and x32.is_contiguous()
+        ops.signal_pack(x32, b["xin"], B, dims.ch, T, Cp)
+        c0, c1, c2 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"], self.conv_ops["conv2"]
+        pb = lambda n: self.pview(f"model.encoder.{n}.bias")  # noqa: E731
+        # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
+        ops.gemm(A=b["xin"], am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
+                 bias=pb("conv1.0"), C16=b["pre0"], c16m=rowmap(d), G16=(b["g0"], d), g16m=rowmap(d, T, (T + 2) * d),
+                 flags=NS_GEMM_GELU)
+        # conv1.2 (k3,s2) + the encoder's outer GELU
+        T2 = T // 2
+        ops.gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
+                 bias=pb("conv1.2"), C16=b["pre1"], c16m=rowmap(d), G16=(b["g1"], d),
+                 g16m=rowmap(d, T2, (T2 + 2) * d), flags=NS_GEMM_GELU)
+        # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
+        h = b["h"]
+        ops.gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
+                 bias=pb("conv2"), C16=b["pre2"], c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
+                 pos_rows=S, flags=NS_GEMM_GELU)
+        dp = self._drop_p()
+        for i, Lw in enumerate(self.enc):
+            j = i if train else 0
+            hin = h[2 * i] if train else h[i % 2 * 0 + (0 if i % 2 == 0 else 1)]
+            if train:
+                hin, hmid, hout = h[2 * i], h[2 * i + 1], h[2 * i + 2]
+            else:
+                hin, hmid, hout = h[0], h[1], h[0]
+            lo = self.lora_ops[i] if r else None
+            seed = self._layer_seed(i)
+            ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
+            if r:
+                ops.gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
+                         c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed)
+                self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j], A2=b["uqkv"][j], lda2=3 * r, K2=r, B2=lo["sBqkv"],
+                          ngroup=d)
+            else:
+                self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j])
+            qkv = b["qkv"][j]
+            ops.attn_fwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][j], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
+                         ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j])
+            if r:
+                ops.gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 1)
+                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"])
+            else:
+                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid)
+            ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
+            if r:
+                ops.gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 2)
+                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j], G16=b["gf"][j], gelu=True, A2=b["u1"][j], lda2=r,
+                          K2=r, B2=lo["fc1_sB"])
+                ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 3)
+                self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
+            else:
+                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j], G16=b["gf"][j], gelu=True)
+                self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout)
+        hlast = h[2 * dims.enc_layers] if train else h[0]
+        b["h_last"] = hlast
+        ops.layernorm_fwd(hlast, *self.enc_ln, b["enc16"], *b["enc_st"], M, d)
+        return b["enc16"]
+
+    def _layer_seed(self, i):
+        return (self._cur_seed + 16 * i) & 0x7FFFFFFF
+
+    def decode_train(self, dec_ids: torch.Tensor, b: dict, train: bool):
+        """Teacher-forced decoder over the whole label sequence -> logits (B*L, Vp) fp16."""
+        dims, d, f, H = self.dims, self.dims.d, self.dims.ffn, self.dims.heads
+        B, L, S = b["B"], b["L"], dims.src_pos
+        M, ML = B * S, B * L
+        hd = b["hd"]
+        ops.embed_pos(dec_ids, self.E32, self.dec_pos, hd[0], ML, L, d)
+        enc16 = b["enc16"]
+        for i, Lw in enumerate(self.dec):
+            j = i if train else 0
+            if train:
+                h0, h1, h2, h3 = hd[3 * i], hd[3 * i + 1], hd[3 * i + 2], hd[3 * i + 3]
+            else:
+                h0, h1, h2, h3 = hd[0], hd[1], hd[0], hd[1]
+                # eval ping-pong: after the layer the stream must be back in hd[0]
+            ops.layernorm_fwd(h0, *Lw["ln1"], b["xs"][j], *b["st_s"][j], ML, d)
+            self._lin(b["xs"][j], ML, Lw["qkv"], C16=b["qkv_s"][j])
+            q = b["qkv_s"][j]
+            ops.attn_fwd(Q=q, K=(q, d), V=(q, 2 * d), O=b["ao_s"][j], B=B, H=H, Lq=L, Lk=L, ldq=3 * d, ldk=3 * d,
+                         ldv=3 * d, ldo=d, causal=True, LSE=b["lse_s"][j])
+            self._lin(b["ao_s"][j], ML, Lw["out"], R32=h0, H32=h1)
+            ops.layernorm_fwd(h1, *Lw["ln2"], b["xc"][j], *b["st_c"][j], ML, d)
+            self._lin(b["xc"][j], ML, Lw["cq"], C16=b["q_c"][j])
+            self._lin(enc16, M, Lw["ckv"], C16=b["kv_c"][j])
+            kv = b["kv_c"][j]
+            ops.attn_fwd(Q=b["q_c"][j], K=kv, V=(kv, d), O=b["ao_c"][j], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
+                         ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][j])
+            self._lin(b["ao_c"][j], ML, Lw["cout"], R32=h1, H32=h2)
+            ops.layernorm_fwd(h2, *Lw["ln3"], b["xm"][j], *b["st_m"][j], ML, d)
+            self._lin(b["xm"][j], ML, Lw["fc1"], C16=b["pre_fd"][j], G16=b["gfd"][j], gelu=True)
+            self._lin(b["gfd"][j], ML, Lw["fc2"], R32=h2, H32=h3)
+            if not train and h3 is not hd[0]:
+                hd[0].copy_(h3)
+        hl = hd[3 * dims.dec_layers] if train else hd[0]
+        b["hd_last"] = hl
+        ops.layernorm_fwd(hl, *self.dec_ln, b["xd"], *b["st_d"], ML, d)
+        Vp = dims.vocab_pad
+        ops.gemm(A=b["xd"], am=rowmap(d), K=d, B=self.E16, ldb=d, M=ML, N=Vp, C16=b["logits"], c16m=rowmap(Vp))
+        return b["logits"]
+
+    @staticmethod
+    def shift_tokens_right(labels: torch.Tensor, pad_id: int, start_id: int) -> torch.Tensor:
+        """HF:modeling_whisper.py:68-81."""
+        out = labels.new_zeros(labels.shape)
+        out[:, 1:] = labels[:, :-1]
+        out[:, 0] = start_id
+        out.masked_fill_(out == -100, pad_id)
+        return out
+
+    def forward(self, x32: torch.Tensor, labels: torch.Tensor | None = None, decoder_input_ids=None,
+                train: bool = False, compute_grad: bool = False):
+        """One forward pass.  Returns (loss_dev or None, logits view (B, L, V))."""
+        dims = self.dims
+        B = x32.shape[0]
+        if decoder_input_ids is None:
+            decoder_input_ids = self.shift_tokens_right(labels, dims.pad_id, dims.start_id)
+        L = decoder_input_ids.shape[1]
+        self.training_mode = train
+        self._cur_seed = (self.drop_seed * 2654435761 + 12345) & 0x7FFFFFFF
+        b = self._alloc(B, L, train)
+        self._b = b
+        self.encode(x32, b, train)
+        logits = self.decode_train(decoder_input_ids.contiguous(), b, train)
+        loss = None
+        if labels is not None:
+            lab = labels.contiguous().view(-1)
+            ops.cross_entropy(logits, lab, B * L, dims.vocab, dims.vocab_pad, b["row_loss"],
+                              logits if compute_grad else None, self.nvalid_dev,
+                              self.loss_scale_dev if compute_grad else None, self.loss_dev)
+            loss = self.loss_dev
+        return loss, logits.view(B, L, dims.vocab_pad)[:, :, :dims.vocab]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, on_ready=None):
+        """Backward of the last forward(train=True, compute_grad=True); logits buffer holds dlogits.
+        Fills self.G (which must have been zeroed).  on_ready(lo, hi) is called when G[lo:hi] is final
+        (chunks in backward-completion order) so the caller can start the RCCL all-reduce early."""
+        b = self._b
+        dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
+        B, L, S, T = b["B"], b["L"], dims.src_pos, dims.T
+        M, ML, Vp = B * S, B * L, dims.vocab_pad
+        hd = b["hd"]
+        # ---- LM head + final decoder LN
+        ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C16=b["ddx16"], c16m=rowmap(d))
+        ops.layernorm_bwd(b["ddx16"], False, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
+                          b["ddh16"], ML, d)
+        first_enc = True
+        for i in reversed(range(dims.dec_layers)):
+            Lw = self.dec[i]
+            h0, h1, h2 = hd[3 * i], hd[3 * i + 1], hd[3 * i + 2]
+            # MLP
+            self._dgrad(b["ddh16"], ML, Lw["fc2"], b["ddpre_f"], P16=b["pre_fd"][i])
+            self._dgrad(b["ddpre_f"], ML, Lw["fc1"], b["ddx16"])
+            ops.layernorm_bwd(b["ddx16"], False, h2, *b["st_m"][i], Lw["ln3"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
+            # cross attention
+            self._dgrad(b["ddh16"], ML, Lw["cout"], b["ddao"])
+            kv = b["kv_c"][i]
+            ops.attn_bwd(Q=b["q_c"][i], K=kv, V=(kv, d), O=b["ao_c"][i], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
+                         ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][i], dO=b["ddao"], dQ=b["ddq_c"], dK=b["dkv_c"],
+                         dV=(b["dkv_c"], d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
+            self._dgrad(b["ddq_c"], ML, Lw["cq"], b["ddx16"])
+            ops.layernorm_bwd(b["ddx16"], False, h1, *b["st_c"][i], Lw["ln2"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
+            # encoder-state gradient accumulates in fp32 across the decoder layers
+            self._dgrad(b["dkv_c"], M, Lw["ckv"], None, R32=None if first_enc else b["denc32"], H32=b["denc32"])
+            first_enc = False
+            # causal self attention
+            self._dgrad(b["ddh16"], ML, Lw["out"], b["ddao"])
+            q = b["qkv_s"][i]
+            dq = b["ddqkv"]
+            ops.attn_bwd(Q=q, K=(q, d), V=(q, 2 * d), O=b["ao_s"][i], B=B, H=H, Lq=L, Lk=L, ldq=3 * d, ldk=3 * d,
+                         ldv=3 * d, ldo=d, causal=True, LSE=b["lse_s"][i], dO=b["ddao"], dQ=dq, dK=(dq, d),
+                         dV=(dq, 2 * d), Delta=b["ddelta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
+            self._dgrad(dq, ML, Lw["qkv"], b["ddx16"])
+            ops.layernorm_bwd(b["ddx16"], False, h0, *b["st_s"][i], Lw["ln1"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
+        # ---- encoder
+        h = b["h"]
+        ops.layernorm_bwd(b["denc32"], True, h[2 * dims.enc_layers], *b["enc_st"], self.enc_ln[0], None, b["dh32"],
+                          b["dh16"], M, d)
+        sc = self.lora.scale if r else 0.0
+        qs = 64 ** -0.5
+        for i in reversed(range(dims.enc_layers)):
+            Lw = self.enc[i]
+            p = f"model.encoder.layers.{i}."
+            hin, hmid = h[2 * i], h[2 * i + 1]
+            lo = self.lora_ops[i] if r else None
+            seed = self._layer_seed(i)
+            dy = b["dh16"]
+            if r:
+                # fc2: du = dy*sB ; dB = s*dy^T u ; dA = du^T gf_d ; dgf = dy*W + mask(du*A)
+                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["fc2_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                self._cur_seed_save = self._cur_seed
+                self._wgrad(dy, d, b["u2"][i], r, M, d, r, p + "fc2.lora_B", alpha=sc)
+                self._with_seed(seed + 3, lambda: self._wgrad(b["du"], r, b["gf"][i], f, M, r, f, p + "fc2.lora_A", drop=True))
+                self._with_seed(seed + 3, lambda: self._dgrad(dy, M, Lw["fc2"], b["dpre_f"], P16=b["pre_f"][i], A2=b["du"],
+                                                               lda2=r, K2=r, B2=lo["fc2_AT"], drop=True))
+                # fc1
+                dpf = b["dpre_f"]
+                ops.gemm(A=dpf, am=rowmap(f), K=f, B=lo["fc1_sBT"], ldb=f, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                self._wgrad(dpf, f, b["u1"][i], r, M, f, r, p + "fc1.lora_B", alpha=sc)
+                self._with_seed(seed + 2, lambda: self._wgrad(b["du"], r, b["x2"][i], d, M, r, d, p + "fc1.lora_A", drop=True))
+                self._with_seed(seed + 2, lambda: self._dgrad(dpf, M, Lw["fc1"], b["dx16"], A2=b["du"], lda2=r, K2=r,
+                                                               B2=lo["fc1_AT"], drop=True))
+            else:
+                self._dgrad(dy, M, Lw["fc2"], b["dpre_f"], P16=b["pre_f"][i])
+                self._dgrad(b["dpre_f"], M, Lw["fc1"], b["dx16"])
+            ops.layernorm_bwd(b["dx16"], False, hmid, *b["st2"][i], Lw["ln2"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
+            dy = b["dh16"]
+            if r:
+                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["out_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                self._wgrad(dy, d, b["uo"][i], r, M, d, r, p + "self_attn.out_proj.lora_B", alpha=sc)
+                self._with_seed(seed + 1, lambda: self._wgrad(b["du"], r, b["ao"][i], d, M, r, d,
+                                                               p + "self_attn.out_proj.lora_A", drop=True))
+                self._with_seed(seed + 1, lambda: self._dgrad(dy, M, Lw["out"], b["dao"], A2=b["du"], lda2=r, K2=r,
+                                                               B2=lo["out_AT"], drop=True))
+            else:
+                self._dgrad(dy, M, Lw["out"], b["dao"])
+            qkv, dqkv = b["qkv"][i], b["dqkv"]
+            ops.attn_bwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][i], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
+                         ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][i], dO=b["dao"], dQ=dqkv, dK=(dqkv, d),
+                         dV=(dqkv, 2 * d), Delta=b["delta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
+            if r:
+                for j, (nm, key, a) in enumerate((("q_proj", "sBqT", sc * qs), ("k_proj", "sBkT", sc), ("v_proj", "sBvT", sc))):
+                    ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=d, B=lo[key], ldb=d, M=M, N=r, C16=(b["du3"], j * r),
+                             c16m=rowmap(3 * r))
+                    ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=M, B=(b["uqkv"][i], j * r), bm=rowmap(3 * r), M=d, N=r,
+                             C32=self.G.data_ptr() + 4 * self.seg_off[p + f"self_attn.{nm}.lora_B"][0], ldc32=r,
+                             flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(M // 256, 192)), alpha=a)
+                self._with_seed(seed, lambda: self._wgrad(b["du3"], 3 * r, b["x1"][i], d, M, 3 * r, d,
+                                                           p + "self_attn.qkv.lora_A", drop=True))
+                self._with_seed(seed, lambda: self._dgrad(dqkv, M, Lw["qkv"], b["dx16"], A2=b["du3"], lda2=3 * r, K2=3 * r,
+                                                           B2=lo["AqkvT"], drop=True))
+            else:
+                self._dgrad(dqkv, M, Lw["qkv"], b["dx16"])
+            ops.layernorm_bwd(b["dx16"], False, hin, *b["st1"][i], Lw["ln1"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
+            if on_ready is not None and r and i in (dims.enc_layers // 2, 0):
+                hi_l = dims.enc_layers - 1 if i == dims.enc_layers // 2 else dims.enc_layers // 2 - 1
+                lo_off = self.seg_off[f"model.encoder.layers.{hi_l}.self_attn.qkv.lora_A"][0]
+                end = self.lora_end if i == 0 else self.seg_off[f"model.encoder.layers.{i - 1}.self_attn.qkv.lora_A"][0]
+                on_ready(lo_off, end)
+        # ---- conv stem (all three convs are trainable: modules_to_save, finetune.py:202)
+        if self.train_convs:
+            self._stem_backward(b)
+        if on_ready is not None:
+            on_ready(self.lora_end, self.n_train)
+
+    def _with_seed(self, seed, fn):
+        save = self._cur_seed
+        self._cur_seed = seed & 0x7FFFFFFF
+        try:
+            fn()
+        finally:
+            self._cur_seed = save
+
+    def _stem_backward(self, b):
+        dims, d = self.dims, self.dims.d
+        B, S, T, Cp = b["B"], dims.src_pos, dims.T, dims.ch_pad
+        T2, M = T // 2, B * S
+        c0, c1, c2 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"], self.conv_ops["conv2"]
+        gp = lambda name: self.G.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
+        # d(pre2) = round16(dh) * gelu'(pre2), halo layout (B, S+2, d)
+        ops.dgelu_mul(b["dh16"], b["pre2"], (b["dpre2"], d), rowmap(d, S, (S + 2) * d), M, d)
+        dp2 = (b["dpre2"], d)
+        hal2 = rowmap(d, S, (S + 2) * d)
+        ops.colsum(b["dpre2"], gp("model.encoder.conv2.bias"), B * (S + 2), d, d)
+        self._wgrad(dp2, 0, b["g1"], 0, M, d, 3 * d, "model.encoder.conv2.wp", am=hal2, bm=rowmap(2 * d, S, (T2 + 2) * d))
+        # dgrad of the stride-2 conv: even output rows (tap 1), odd rows (taps 2|0 over dy[i], dy[i+1])
+        ev = rowmap(2 * d, S, T2 * d)
+        ops.gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=b["dg1"], c16m=ev, P16=b["pre1"], p16m=ev,
+                 flags=NS_GEMM_DGELU)
+        ops.gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dg1"], d), c16m=ev,
+                 P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_DGELU)
+        # dg1 now holds d(pre1) (gelu' already applied) in plain layout -> copy into the halo layout buffer
+        b["dpre1"].view(B, T2 + 2, d)[:, 1:T2 + 1].copy_(b["dg1"].view(B, T2, d))
+        dp1 = (b["dpre1"], d)
+        hal1 = rowmap(d, T2, (T2 + 2) * d)
+        ops.colsum(b["dpre1"], gp("model.encoder.conv1.2.bias"), B * (T2 + 2), d, d)
+        self._wgrad(dp1, 0, b["g0"], 0, B * T2, d, 3 * d, "model.encoder.conv1.2.wp", am=hal1,
+                    bm=rowmap(2 * d, T2, (T + 2) * d))
+        ev = rowmap(2 * d, T2, T * d)
+        ops.gemm(A=dp1, am=hal1, K=d, B=c1["we"], ldb=d, M=B * T2, N=d, C16=b["dpre0"], c16m=ev, P16=b["pre0"], p16m=ev,
+                 flags=NS_GEMM_DGELU)
+        ops.gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
+                 P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_DGELU)
+        ops.colsum(b["dpre0"], gp("model.encoder.conv1.0.bias"), B * T, d, d)
+        self._wgrad(b["dpre0"], 0, b["xin"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
+                    bm=rowmap(Cp, T, (T + 2) * Cp))
+
+    # ------------------------------------------------------------------ optimizer
+    def zero_grad(self):
+        self.G.zero_()
+
+    def optimizer_step(self):
+        tc = self.tc
+        cfg = AdamWCfg(tc.lr, tc.beta1, tc.beta2, tc.eps, tc.weight_decay, tc.max_grad_norm, tc.warmup_steps,
+                       tc.total_steps, tc.growth_factor, tc.backoff_factor, tc.growth_interval)
+        ops.grad_norm(self.G, self.n_train, self.norm_ws, self.norm2_dev, self.found_inf_dev)
+        ops.adamw_step(self.P, self.G, self.M1, self.M2, self.n_train, cfg, self.step_dev, self.norm2_dev,
+                       self.found_inf_dev, self.loss_scale_dev if tc.fp16_scaler else None,
+                       self.growth_dev if tc.fp16_scaler else None)
+        self.refresh_operands()
+        self.drop_seed += 1
+
+    def train_step(self, x32, labels, on_ready=None, reduce_fn=None):
+        """forward + backward (+ optional gradient reduction) + optimizer; returns the device loss scalar."""
+        self.zero_grad()
+        loss, _ = self.forward(x32, labels, train=True, compute_grad=True)
+        self.backward(on_ready)
+        if reduce_fn is not None:
+            reduce_fn()
+        self.optimizer_step()
+        return loss
+
+    # ------------------------------------------------------------------ export
+    def conv_weight(self, name: str) -> torch.Tensor:
+        """torch-layout (N, C, 3) view of a packed conv master (name in conv1.0 / conv1.2 / conv2)."""
+        d = self.dims.d
+        cin, cp = (self.dims.ch, self.dims.ch_pad) if name == "conv1.0" else (d, d)
+        return self.pview(f"model.encoder.{name}.wp").view(d, 3, cp).permute(0, 2, 1)[:, :cin, :]
+
+    def conv_weight_grad(self, name: str) -> torch.Tensor:
+        d = self.dims.d
+        cin, cp = (self.dims.ch, self.dims.ch_pad) if name == "conv1.0" else (d, d)
+        return self.gview(f"model.encoder.{name}.wp").view(d, 3, cp).permute(0, 2, 1)[:, :cin, :]

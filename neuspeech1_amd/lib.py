@@ -1,0 +1,130 @@
+"""ctypes binding of libneuspeech_hip.so (the C ABI in include/neuspeech_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a symbol
+is absent, importing/using the product path raises.  The oracle under oracle/
+is test infrastructure and is never reachable from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneuspeech_hip.so")
+
+
+class NeuSpeechHipError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("seg_stride", C.c_int64), ("seg_rows", C.c_int32), ("ld", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("am", RowMap), ("K", C.c_int32),
+        ("B", C.c_void_p), ("bm", RowMap),
+        ("A2", C.c_void_p), ("am2", RowMap), ("K2", C.c_int32),
+        ("B2", C.c_void_p), ("ldb2", C.c_int32),
+        ("a2_ngroup", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32),
+        ("bias", C.c_void_p),
+        ("C16", C.c_void_p), ("c16m", RowMap),
+        ("G16", C.c_void_p), ("g16m", RowMap),
+        ("P16", C.c_void_p), ("p16m", RowMap),
+        ("R32", C.c_void_p), ("H32", C.c_void_p), ("h32m", RowMap),
+        ("pos", C.c_void_p), ("pos_rows", C.c_int32),
+        ("C32", C.c_void_p), ("ldc32", C.c_int32),
+        ("flags", C.c_int32),
+        ("splits", C.c_int32),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+        ("alpha", C.c_float),
+    ]
+
+
+class CastJob(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("rows", C.c_int32), ("cols", C.c_int32), ("ld_src", C.c_int32), ("ld_dst", C.c_int32),
+        ("scale", C.c_float), ("transpose", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+        ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("LSE", C.c_void_p), ("Delta", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("head_dim", C.c_int32),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+        ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
+        ("causal", C.c_int32),
+    ]
+
+
+class AdamWCfg(C.Structure):
+    _fields_ = [
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("weight_decay", C.c_float), ("max_grad_norm", C.c_float),
+        ("warmup_steps", C.c_int32), ("total_steps", C.c_int32),
+        ("scale_growth", C.c_float), ("scale_backoff", C.c_float), ("scale_interval", C.c_int32),
+    ]
+
+
+NS_GEMM_GELU, NS_GEMM_DGELU, NS_GEMM_TN, NS_GEMM_ATOMIC32, NS_GEMM_DROP_A = 1, 2, 4, 8, 16
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol the header declares is listed here
+# and checked at load time (tests/test_abi.py also cross-checks the header text).
+SIGNATURES = {
+    "ns_version": (C.c_int, []),
+    "ns_last_error": (C.c_char_p, []),
+    "ns_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ns_embed_pos": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _vp]),
+    "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
+    "ns_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ns_argmax_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "ns_grad_norm_workspace_bytes": (C.c_size_t, []),
+    "ns_grad_norm": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    "ns_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.POINTER(AdamWCfg), _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object; raise loudly when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NeuSpeechHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the product path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise NeuSpeechHipError(f"libneuspeech_hip.so lacks symbol {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ns_version() != 1:
+        raise NeuSpeechHipError(f"ABI version mismatch: {lib.ns_version()}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ns_last_error().decode("utf-8", "replace")
+        raise NeuSpeechHipError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,145 @@
+"""Thin torch-tensor front end over the C ABI (ctypes).  PyTorch supplies device
+memory and streams only; every FLOP happens in libneuspeech_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import (AdamWCfg, AttnDesc, CastJob, GemmDesc, RowMap, NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A,
+                  NS_GEMM_GELU, NS_GEMM_TN)
+
+__all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pack", "embed_pos", "attn_fwd",
+           "attn_bwd", "cross_entropy", "dgelu_mul", "colsum", "argmax_rows", "grad_norm", "adamw_step", "cast_jobs", "make_cast_jobs",
+           "NS_GEMM_GELU", "NS_GEMM_DGELU", "NS_GEMM_TN", "NS_GEMM_ATOMIC32", "NS_GEMM_DROP_A"]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, off: int = 0) -> int:
+    """Device address of tensor element `off` (0 for None)."""
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    if isinstance(t, tuple):
+        t, off = t
+    return t.data_ptr() + off * t.element_size()
+
+
+def rowmap(ld: int, seg_rows: int = 0, seg_stride: int = 0) -> RowMap:
+    return RowMap(int(seg_stride), int(seg_rows), int(ld))
+
+
+_ZERO_MAP = RowMap(0, 0, 0)
+
+
+def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
+         bias=None, C16=None, c16m=None, G16=None, g16m=None, P16=None, p16m=None, R32=None, H32=None, h32m=None,
+         pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0):
+    d = GemmDesc()
+    d.A, d.am, d.K = ptr(A), am, K
+    d.B = ptr(B)
+    d.bm = bm if bm is not None else rowmap(ldb)
+    d.A2, d.am2, d.K2 = ptr(A2), (am2 if am2 is not None else _ZERO_MAP), K2
+    d.B2, d.ldb2, d.a2_ngroup = ptr(B2), ldb2, a2_ngroup
+    d.M, d.N = M, N
+    d.bias = ptr(bias)
+    d.C16, d.c16m = ptr(C16), (c16m if c16m is not None else _ZERO_MAP)
+    d.G16, d.g16m = ptr(G16), (g16m if g16m is not None else _ZERO_MAP)
+    d.P16, d.p16m = ptr(P16), (p16m if p16m is not None else _ZERO_MAP)
+    d.R32, d.H32, d.h32m = ptr(R32), ptr(H32), (h32m if h32m is not None else _ZERO_MAP)
+    d.pos, d.pos_rows = ptr(pos), pos_rows
+    d.C32, d.ldc32 = ptr(C32), ldc32
+    d.flags, d.splits = flags, splits
+    d.drop_p, d.drop_seed, d.alpha = drop_p, drop_seed, alpha
+    L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
+
+
+def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5):
+    L.check(L.load().ns_layernorm_fwd(ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean), ptr(rstd),
+                                      rows, d, eps, _stream()), "ns_layernorm_fwd")
+
+
+def layernorm_bwd(dy, dy_is_f32, x32, mean, rstd, gamma, dres, dx32, dx16, rows, d):
+    L.check(L.load().ns_layernorm_bwd(ptr(dy), int(dy_is_f32), ptr(x32), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
+                                      ptr(dx32), ptr(dx16), rows, d, _stream()), "ns_layernorm_bwd")
+
+
+def signal_pack(x32, out16, B, ch, T, Cp):
+    L.check(L.load().ns_signal_pack(ptr(x32), ptr(out16), B, ch, T, Cp, _stream()), "ns_signal_pack")
+
+
+def embed_pos(ids, E32, P32, h32, rows, Lseq, d, pos0=0, pos0_dev=None):
+    L.check(L.load().ns_embed_pos(ptr(ids), ptr(E32), ptr(P32), ptr(h32), rows, Lseq, d, pos0, ptr(pos0_dev),
+                                  _stream()), "ns_embed_pos")
+
+
+def dgelu_mul(a16, pre16, out16, out_map, rows, cols):
+    L.check(L.load().ns_dgelu_mul(ptr(a16), ptr(pre16), ptr(out16), C.byref(out_map), rows, cols, _stream()),
+            "ns_dgelu_mul")
+
+
+def colsum(a16, out32, rows, cols, ld, alpha=1.0):
+    L.check(L.load().ns_colsum(ptr(a16), ptr(out32), rows, cols, ld, alpha, _stream()), "ns_colsum")
+
+
+def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, dO=None, dQ=None, dK=None, dV=None,
+               Delta=None, lddo=0, lddq=0, lddk=0, lddv=0):
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = ptr(Q), ptr(K), ptr(V), ptr(O)
+    d.dO, d.dQ, d.dK, d.dV = ptr(dO), ptr(dQ), ptr(dK), ptr(dV)
+    d.LSE, d.Delta = ptr(LSE), ptr(Delta)
+    d.B, d.H, d.Lq, d.Lk, d.head_dim = B, H, Lq, Lk, 64
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
+    d.lddo, d.lddq, d.lddk, d.lddv = lddo, lddq, lddk, lddv
+    d.causal = int(causal)
+    return d
+
+
+def attn_fwd(**kw):
+    d = _attn_desc(**kw)
+    L.check(L.load().ns_attn_fwd(C.byref(d), _stream()), "ns_attn_fwd")
+
+
+def attn_bwd(**kw):
+    d = _attn_desc(**kw)
+    L.check(L.load().ns_attn_bwd(C.byref(d), _stream()), "ns_attn_bwd")
+
+
+def cross_entropy(logits16, labels, rows, V, ldv, row_loss, dlogits16, nvalid_dev, loss_scale_dev, loss_dev):
+    L.check(L.load().ns_cross_entropy(ptr(logits16), ptr(labels), rows, V, ldv, ptr(row_loss), ptr(dlogits16),
+                                      ptr(nvalid_dev), ptr(loss_scale_dev), ptr(loss_dev), _stream()),
+            "ns_cross_entropy")
+
+
+def argmax_rows(logits16, rows, V, ldv, out):
+    L.check(L.load().ns_argmax_rows(ptr(logits16), rows, V, ldv, ptr(out), _stream()), "ns_argmax_rows")
+
+
+def grad_norm(g32, n, workspace, norm2_dev, found_inf_dev):
+    L.check(L.load().ns_grad_norm(ptr(g32), n, ptr(workspace), ptr(norm2_dev), ptr(found_inf_dev), _stream()),
+            "ns_grad_norm")
+
+
+def adamw_step(p, g, m, v, n, cfg: AdamWCfg, step_dev, norm2_dev, found_inf_dev, loss_scale_dev, growth_tracker_dev):
+    L.check(L.load().ns_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), n, C.byref(cfg), ptr(step_dev), ptr(norm2_dev),
+                                   ptr(found_inf_dev), ptr(loss_scale_dev), ptr(growth_tracker_dev), _stream()),
+            "ns_adamw_step")
+
+
+def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
+    """jobs: list of (src_ptr, dst_ptr, rows, cols, ld_src, ld_dst, scale, transpose) -> device table."""
+    arr = (CastJob * len(jobs))()
+    for i, (s, dptr, r, c, lds, ldd, sc, tr) in enumerate(jobs):
+        arr[i] = CastJob(s, dptr, r, c, lds, ldd, sc, int(tr))
+    raw = bytes(arr)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return t, len(jobs)
+
+
+def cast_jobs(table: torch.Tensor, njobs: int):
+    L.check(L.load().ns_cast_jobs(ptr(table), njobs, _stream()), "ns_cast_jobs")

@@ -1,0 +1,326 @@
+"""Per-kernel parity of libneuspeech_hip (through the C ABI) against plain torch
+fp32 math on the same device.  Tolerances are stated per test: fp16 outputs
+carry 2^-11 relative rounding, fp32 accumulation order differs from rocBLAS."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from neuspeech1_amd import ops as o
+    return o
+
+
+def rnd(shape, dev, scale=1.0, dtype=torch.float16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def close(a, b, atol, rtol, what=""):
+    a = a.float()
+    b = b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} off, max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+# --------------------------------------------------------------------------- GEMM
+def test_gemm_integer_exact_layout(ops, dev):
+    """A=I-style check with ASYMMETRIC integer data: catches transposed / permuted MFMA layouts exactly."""
+    M, N, K = 256, 384, 128
+    A = ((torch.arange(M * K, device=dev).reshape(M, K) * 7 + 3) % 5 - 2).half()
+    B = ((torch.arange(N * K, device=dev).reshape(N, K) * 11 + 1) % 7 - 3).half()
+    Cout = torch.zeros(M, N, device=dev, dtype=torch.float16)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=Cout, c16m=ops.rowmap(N))
+    ref = A.float() @ B.float().T
+    assert torch.equal(Cout.float(), ref), f"max diff {(Cout.float() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 1536, 512), (77, 96, 512), (513, 32, 2048)])
+def test_gemm_nt_bias(ops, dev, M, N, K):
+    A, B = rnd((M, K), dev, 1.0, seed=1), rnd((N, K), dev, 0.05, seed=2)
+    bias = rnd((N,), dev, 0.5, torch.float32, seed=3)
+    Cout = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=Cout, c16m=ops.rowmap(N))
+    ref = A.float() @ B.float().T + bias
+    close(Cout, ref, 2e-3 * math.sqrt(K / 64), 2e-3, "gemm_nt")
+
+
+def test_gemm_epilogues(ops, dev):
+    M, N, K, S = 384, 256, 128, 96
+    A, B = rnd((M, K), dev, seed=1), rnd((N, K), dev, 0.1, seed=2)
+    bias = rnd((N,), dev, 0.2, torch.float32, seed=3)
+    R = rnd((M, N), dev, 1.0, torch.float32, seed=4)
+    pos = rnd((S, N), dev, 1.0, torch.float32, seed=5)
+    C16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+    G16 = torch.empty_like(C16)
+    H = torch.empty(M, N, device=dev, dtype=torch.float32)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=C16, c16m=ops.rowmap(N), G16=G16,
+             g16m=ops.rowmap(N), R32=R, H32=H, h32m=ops.rowmap(N), pos=pos, pos_rows=S, flags=ops.NS_GEMM_GELU)
+    v16 = (A.float() @ B.float().T + bias).half()
+    close(C16, v16, 3e-3, 2e-3, "C16")
+    g = F.gelu(C16.float()).half()  # gelu of the kernel's own rounded value: isolates the epilogue
+    close(G16, g, 1e-3, 1e-3, "G16")
+    href = R + G16.float() + pos.repeat(M // S, 1)
+    close(H, href, 1e-5, 1e-6, "H32")
+    # in-place residual, no gelu
+    H2 = R.clone()
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, R32=H2, H32=H2, h32m=ops.rowmap(N))
+    close(H2, R + v16.float(), 4e-3, 2e-3, "H32 inplace")
+    # dgelu
+    P = rnd((M, N), dev, 1.0, seed=6)
+    D = torch.empty_like(C16)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N),
+             flags=ops.NS_GEMM_DGELU)
+    x = P.float().requires_grad_(True)
+    F.gelu(x).backward((A.float() @ B.float().T).half().float())
+    close(D, x.grad, 4e-3, 3e-3, "dgelu")
+
+
+def test_gemm_second_product_groups(ops, dev):
+    """fused q|k|v projection with three LoRA-A outputs side by side (a2_ngroup)."""
+    M, d, r = 260, 256, 32
+    x = rnd((M, d), dev, seed=1)
+    W = rnd((3 * d, d), dev, 0.05, seed=2)
+    u = rnd((M, 3 * r), dev, 0.5, seed=3)
+    Bs = rnd((3 * d, r), dev, 0.1, seed=4)
+    out = torch.empty(M, 3 * d, device=dev, dtype=torch.float16)
+    ops.gemm(A=x, am=ops.rowmap(d), K=d, B=W, ldb=d, M=M, N=3 * d, A2=u, am2=ops.rowmap(3 * r), K2=r, B2=Bs, ldb2=r,
+             a2_ngroup=d, C16=out, c16m=ops.rowmap(3 * d))
+    ref = x.float() @ W.float().T
+    for g in range(3):
+        ref[:, g * d:(g + 1) * d] += u[:, g * r:(g + 1) * r].float() @ Bs[g * d:(g + 1) * d].float().T
+    close(out, ref, 4e-3, 3e-3, "gemm 2nd product")
+    # K2 = 16 (AdaLoRA r=12 padded) without groups
+    u2, B2 = rnd((M, 16), dev, 0.5, seed=5), rnd((d, 16), dev, 0.1, seed=6)
+    out2 = torch.empty(M, d, device=dev, dtype=torch.float16)
+    ops.gemm(A=x, am=ops.rowmap(d), K=d, B=W, ldb=d, M=M, N=d, A2=u2, am2=ops.rowmap(16), K2=16, B2=B2, ldb2=16,
+             C16=out2, c16m=ops.rowmap(d))
+    close(out2, x.float() @ W[:d].float().T + u2.float() @ B2.float().T, 4e-3, 3e-3, "gemm K2=16")
+
+
+@pytest.mark.parametrize("stride,T,Cin", [(1, 128, 64), (2, 256, 128), (2, 1000, 64)])
+def test_gemm_conv_rowmap(ops, dev, stride, T, Cin):
+    """k=3 Conv1d as ONE GEMM over the halo-padded token-major activation (overlapping rows)."""
+    Bn, Cout = 3, 128
+    Tout = T // stride
+    x = rnd((Bn, Cin, T), dev, 1.0, torch.float32, seed=1)
+    w = rnd((Cout, Cin, 3), dev, 0.1, torch.float32, seed=2)
+    b = rnd((Cout,), dev, 0.1, torch.float32, seed=3)
+    xh = torch.zeros(Bn, T + 2, Cin, device=dev, dtype=torch.float16)
+    xh[:, 1:T + 1] = x.transpose(1, 2).half()
+    wg = w.permute(0, 2, 1).reshape(Cout, 3 * Cin).half().contiguous()   # [n][(tap, c)]
+    out = torch.zeros(Bn, Tout + 2, Cout, device=dev, dtype=torch.float16)
+    ops.gemm(A=xh, am=ops.rowmap(stride * Cin, Tout, (T + 2) * Cin), K=3 * Cin, B=wg, ldb=3 * Cin, M=Bn * Tout,
+             N=Cout, bias=b, C16=(out, Cout), c16m=ops.rowmap(Cout, Tout, (Tout + 2) * Cout))
+    ref = F.conv1d(xh[:, 1:T + 1].float().transpose(1, 2), wg.float().reshape(Cout, 3, Cin).permute(0, 2, 1), b,
+                   stride=stride, padding=1).transpose(1, 2)
+    close(out[:, 1:Tout + 1], ref, 5e-3, 3e-3, "conv-as-gemm")
+    assert out[:, 0].abs().max() == 0 and out[:, Tout + 1].abs().max() == 0, "halo rows must stay zero"
+
+
+@pytest.mark.parametrize("Mred,No,Ko,splits", [(512, 128, 128, 1), (1000, 256, 96, 4), (3000, 64, 32, 7), (4096, 96, 512, 16)])
+def test_gemm_tn(ops, dev, Mred, No, Ko, splits):
+    dY, X = rnd((Mred, No), dev, 0.5, seed=1), rnd((Mred, Ko), dev, 0.5, seed=2)
+    out = torch.zeros(No, Ko, device=dev, dtype=torch.float32)
+    ops.gemm(A=dY, am=ops.rowmap(No), K=Mred, B=X, bm=ops.rowmap(Ko), M=No, N=Ko, C32=out, ldc32=Ko,
+             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=splits, alpha=2.0)
+    ref = 2.0 * dY.float().T @ X.float()
+    close(out, ref, 2e-2, 2e-3, "gemm_tn")
+
+
+def test_gemm_tn_conv_wgrad(ops, dev):
+    """weight gradient of the stride-2 conv = dY^T * overlapping-row view, segmented per batch item."""
+    Bn, T, Cin, Cout, stride = 3, 200, 64, 128, 2
+    Tout = T // stride
+    xh = torch.zeros(Bn, T + 2, Cin, device=dev, dtype=torch.float16)
+    xh[:, 1:T + 1] = rnd((Bn, T, Cin), dev, 1.0, seed=1)
+    dy = rnd((Bn * Tout, Cout), dev, 0.5, seed=2)
+    out = torch.zeros(Cout, 3 * Cin, device=dev, dtype=torch.float32)
+    ops.gemm(A=dy, am=ops.rowmap(Cout, Tout, Tout * Cout), K=Bn * Tout, B=xh,
+             bm=ops.rowmap(stride * Cin, Tout, (T + 2) * Cin), M=Cout, N=3 * Cin, C32=out, ldc32=3 * Cin,
+             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=3)
+    w = torch.zeros(Cout, Cin, 3, device=dev, requires_grad=True)
+    y = F.conv1d(xh[:, 1:T + 1].float().transpose(1, 2), w, None, stride=stride, padding=1)
+    y.backward(dy.float().reshape(Bn, Tout, Cout).transpose(1, 2))
+    ref = w.grad.permute(0, 2, 1).reshape(Cout, 3 * Cin)
+    close(out, ref, 2e-2, 2e-3, "conv wgrad")
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,d", [(37, 256), (1000, 512), (130, 1280)])
+def test_layernorm(ops, dev, rows, d):
+    x = rnd((rows, d), dev, 2.0, torch.float32, seed=1) + 0.5
+    g = rnd((d,), dev, 1.0, torch.float32, seed=2)
+    b = rnd((d,), dev, 1.0, torch.float32, seed=3)
+    y16 = torch.empty(rows, d, device=dev, dtype=torch.float16)
+    y32 = torch.empty(rows, d, device=dev, dtype=torch.float32)
+    mean = torch.empty(rows, device=dev)
+    rstd = torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x, g, b, y16, mean, rstd, rows, d, y32=y32)
+    xr = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,), g, b, 1e-5)
+    close(y32, ref, 2e-5, 1e-5, "ln fwd32")
+    close(y16, ref.half(), 1e-3, 1e-3, "ln fwd16")
+    for is32 in (False, True):
+        dy = rnd((rows, d), dev, 1.0, torch.float32 if is32 else torch.float16, seed=4)
+        dres = rnd((rows, d), dev, 1.0, torch.float32, seed=5)
+        dx32 = torch.empty(rows, d, device=dev)
+        dx16 = torch.empty(rows, d, device=dev, dtype=torch.float16)
+        ops.layernorm_bwd(dy, is32, x, mean, rstd, g, dres, dx32, dx16, rows, d)
+        xr.grad = None
+        ref.backward(dy.float(), retain_graph=True)
+        close(dx32, xr.grad + dres, 3e-4, 1e-4, "ln bwd")
+        close(dx16, dx32.half(), 1e-6, 1e-6, "ln bwd16")
+
+
+# --------------------------------------------------------------------------- byte movers
+@pytest.mark.parametrize("ch,T", [(208, 6000), (273, 6000), (10, 100)])
+def test_signal_pack(ops, dev, ch, T):
+    Bn = 2
+    Cp = (ch + 63) // 64 * 64
+    x = rnd((Bn, ch, T), dev, 0.35, torch.float32, seed=1).clamp(-1, 1)
+    out = torch.full((Bn, T + 2, Cp), float("nan"), device=dev, dtype=torch.float16)
+    ops.signal_pack(x, out, Bn, ch, T, Cp)
+    ref = torch.zeros(Bn, T + 2, Cp, device=dev, dtype=torch.float16)
+    ref[:, 1:T + 1, :ch] = x.transpose(1, 2).half()
+    assert torch.equal(out, ref)
+
+
+def test_embed_cast_dgelu_colsum(ops, dev):
+    V, d, Bn, Lq = 500, 256, 3, 7
+    E, P = rnd((V, d), dev, 1.0, torch.float32, seed=1), rnd((448, d), dev, 1.0, torch.float32, seed=2)
+    ids = torch.randint(0, V, (Bn, Lq), device=dev)
+    h = torch.empty(Bn * Lq, d, device=dev)
+    ops.embed_pos(ids, E, P, h, Bn * Lq, Lq, d, pos0=3)
+    assert torch.equal(h.reshape(Bn, Lq, d), E[ids] + P[3:3 + Lq])
+    # cast jobs
+    src = rnd((70, 45), dev, 1.0, torch.float32, seed=3)
+    d1 = torch.zeros(70, 48, device=dev, dtype=torch.float16)
+    d2 = torch.zeros(45, 72, device=dev, dtype=torch.float16)
+    tab, n = ops.make_cast_jobs([(src.data_ptr(), d1.data_ptr(), 70, 45, 45, 48, 2.0, 0),
+                                 (src.data_ptr(), d2.data_ptr(), 70, 45, 45, 72, 0.5, 1)], dev)
+    ops.cast_jobs(tab, n)
+    assert torch.equal(d1[:, :45], (2.0 * src).half()) and torch.equal(d2[:, :70], (0.5 * src).half().T)
+    # dgelu_mul into a halo layout + colsum
+    rows, cols, seg = 128, 64, 64
+    a, pre = rnd((rows, cols), dev, 1.0, seed=4), rnd((rows, cols), dev, 1.0, seed=5)
+    out = torch.zeros(2, seg + 2, cols, device=dev, dtype=torch.float16)
+    ops.dgelu_mul(a, pre, (out, cols), ops.rowmap(cols, seg, (seg + 2) * cols), rows, cols)
+    x = pre.float().requires_grad_(True)
+    F.gelu(x).backward(a.float())
+    close(out[:, 1:seg + 1].reshape(rows, cols), x.grad, 2e-3, 2e-3, "dgelu_mul")
+    cs = torch.zeros(cols, device=dev)
+    ops.colsum(a, cs, rows, cols, cols, 0.5)
+    close(cs, 0.5 * a.float().sum(0), 1e-3, 1e-4, "colsum")
+
+
+# --------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, causal):
+    # q,k,v: (B, L, H, 64) fp32 ; returns (B, Lq, H, 64)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k)
+    if causal:
+        Lq, Lk = q.shape[1], k.shape[1]
+        i = torch.arange(Lq, device=q.device)[:, None]
+        j = torch.arange(Lk, device=q.device)[None, :]
+        s = s.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    p = s.softmax(-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("Bn,H,Lq,Lk,causal", [(2, 4, 1500, 1500, False), (3, 2, 40, 40, True), (2, 4, 37, 1500, False),
+                                                (2, 2, 1, 29, True), (1, 2, 200, 200, True)])
+def test_attention_fwd_bwd(ops, dev, Bn, H, Lq, Lk, causal):
+    d = H * 64
+    # q lives in a fused (q|k|v)-style buffer to exercise row strides
+    qkv = rnd((Bn * Lq, 3 * d), dev, 0.3, seed=1)
+    kv = rnd((Bn * Lk, 2 * d), dev, 0.6, seed=2)
+    O = torch.zeros(Bn * Lq, d, device=dev, dtype=torch.float16)
+    LSE = torch.zeros(Bn, H, Lq, device=dev)
+    common = dict(Q=qkv, K=kv, V=(kv, d), O=O, B=Bn, H=H, Lq=Lq, Lk=Lk, ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d,
+                  causal=causal, LSE=LSE)
+    ops.attn_fwd(**common)
+    q = qkv[:, :d].float().reshape(Bn, Lq, H, 64).requires_grad_(True)
+    k = kv[:, :d].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+    v = kv[:, d:].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+    ref, lse_ref = attn_ref(q, k, v, causal)
+    close(O.reshape(Bn, Lq, H, 64), ref, 3e-3, 1e-2, "attn fwd")
+    close(LSE, lse_ref, 2e-3, 1e-3, "lse")
+    dO = rnd((Bn * Lq, d), dev, 0.5, seed=3)
+    dQ = torch.zeros(Bn * Lq, 3 * d, device=dev, dtype=torch.float16)
+    dKV = torch.zeros(Bn * Lk, 2 * d, device=dev, dtype=torch.float16)
+    Delta = torch.zeros(Bn, H, Lq, device=dev)
+    ops.attn_bwd(**common, dO=dO, dQ=dQ, dK=dKV, dV=(dKV, d), Delta=Delta, lddo=d, lddq=3 * d, lddk=2 * d, lddv=2 * d)
+    ref.backward(dO.float().reshape(Bn, Lq, H, 64))
+    sc = max(1.0, math.sqrt(Lq / 64))
+    close(dQ[:, :d].reshape(Bn, Lq, H, 64), q.grad, 4e-3, 2e-2, "dQ")
+    close(dKV[:, :d].reshape(Bn, Lk, H, 64), k.grad, 4e-3 * sc, 2e-2, "dK")
+    close(dKV[:, d:].reshape(Bn, Lk, H, 64), v.grad, 4e-3 * sc, 2e-2, "dV")
+    assert dQ[:, d:].abs().max() == 0, "attention must not write outside its head columns"
+
+
+# --------------------------------------------------------------------------- loss / optimizer
+def test_cross_entropy_and_argmax(ops, dev):
+    rows, V, ldv = 50, 51865, 51968
+    logits = torch.zeros(rows, ldv, device=dev, dtype=torch.float16)
+    logits[:, :V] = rnd((rows, V), dev, 2.0, seed=1)
+    logits[:, V:] = 7.0  # padding columns must be ignored
+    labels = torch.randint(0, V, (rows,), device=dev)
+    labels[::7] = -100
+    row_loss = torch.empty(rows, device=dev)
+    dl = torch.empty_like(logits)
+    nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
+    loss = torch.zeros(1, device=dev)
+    scale = torch.tensor([1024.0], device=dev)
+    ops.cross_entropy(logits, labels, rows, V, ldv, row_loss, dl, nvalid, scale, loss)
+    x = logits[:, :V].float().requires_grad_(True)
+    ref = F.cross_entropy(x, labels, ignore_index=-100)
+    (ref * 1024.0).backward()
+    assert nvalid.item() == (labels != -100).sum().item()
+    close(loss, ref.reshape(1), 1e-4, 1e-5, "loss")
+    close(dl[:, :V], x.grad, 2e-3, 2e-3, "dlogits")
+    assert dl[:, V:].abs().max() == 0
+    am = torch.empty(rows, device=dev, dtype=torch.int64)
+    ops.argmax_rows(logits, rows, V, ldv, am)
+    assert torch.equal(am, logits[:, :V].float().argmax(-1))
+
+
+def test_adamw_clip_scaler(ops, dev):
+    from neuspeech1_amd.lib import AdamWCfg
+    n = 100_003
+    p0 = rnd((n,), dev, 1.0, torch.float32, seed=1)
+    p = p0.clone()
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: s / 3 if s < 3 else max(0.0, (10 - s) / (10 - 3)))
+    cfg = AdamWCfg(1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 3, 10, 2.0, 0.5, 2000)
+    step = torch.zeros(1, device=dev, dtype=torch.int32)
+    norm2 = torch.zeros(1, device=dev)
+    finf = torch.zeros(1, device=dev, dtype=torch.int32)
+    scale = torch.tensor([65536.0], device=dev)
+    tracker = torch.zeros(1, device=dev, dtype=torch.int32)
+    ws = torch.empty(8192, device=dev, dtype=torch.uint8)
+    for it in range(6):
+        g_true = rnd((n,), dev, 0.05, torch.float32, seed=10 + it)
+        g = g_true * scale  # what the scaled backward leaves in the buffer
+        if it == 2:
+            g[5] = float("inf")
+        ops.grad_norm(g, n, ws, norm2, finf)
+        ops.adamw_step(p, g, m, v, n, cfg, step, norm2, finf, scale, tracker)
+        if it == 2:
+            assert finf.item() == 1 and scale.item() == 32768.0
+            continue
+        ref_p.grad = g_true.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        sched.step()
+    assert step.item() == 5
+    close(p, ref_p.detach(), 2e-6, 2e-5, "adamw")
