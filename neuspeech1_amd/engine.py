@@ -351,9 +351,7 @@ class MegWhisperEngine:
             b["ddpre_f"] = h16(ML, f)
             b["ddelta"] = f32(B, H, L)
             b["dpre2"] = h16(B, S + 2, d)
-            b["dg1"] = h16(B * T // 2, d)
             b["dpre1"] = h16(B, T // 2 + 2, d)
-            b["dg0"] = h16(B * T, d)
             b["dpre0"] = h16(B * T, d)
         self._bufs[key] = b
         return b
@@ -669,13 +667,13 @@ class MegWhisperEngine:
         ops.colsum(b["dpre2"], gp("model.encoder.conv2.bias"), B * (S + 2), d, d)
         self._wgrad(dp2, 0, b["g1"], 0, M, d, 3 * d, "model.encoder.conv2.wp", am=hal2, bm=rowmap(2 * d, S, (T2 + 2) * d))
         # dgrad of the stride-2 conv: even output rows (tap 1), odd rows (taps 2|0 over dy[i], dy[i+1])
+        # gelu'(pre1) is applied in the epilogue; results land directly in the halo layout of d(pre1)
         ev = rowmap(2 * d, S, T2 * d)
-        ops.gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=b["dg1"], c16m=ev, P16=b["pre1"], p16m=ev,
-                 flags=NS_GEMM_DGELU)
-        ops.gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dg1"], d), c16m=ev,
+        evh = rowmap(2 * d, S, (T2 + 2) * d)
+        ops.gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=(b["dpre1"], d), c16m=evh, P16=b["pre1"],
+                 p16m=ev, flags=NS_GEMM_DGELU)
+        ops.gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dpre1"], 2 * d), c16m=evh,
                  P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_DGELU)
-        # dg1 now holds d(pre1) (gelu' already applied) in plain layout -> copy into the halo layout buffer
-        b["dpre1"].view(B, T2 + 2, d)[:, 1:T2 + 1].copy_(b["dg1"].view(B, T2, d))
         dp1 = (b["dpre1"], d)
         hal1 = rowmap(d, T2, (T2 + 2) * d)
         ops.colsum(b["dpre1"], gp("model.encoder.conv1.2.bias"), B * (T2 + 2), d, d)

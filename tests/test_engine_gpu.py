@@ -1,0 +1,160 @@
+"""Whole-path parity on the GPU: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs, and against the golden vectors of the reference object (tests/golden, tools/make_goldens.py).
+
+Tolerances (fp16 GEMM operands / fp16-rounded Linear outputs vs an fp32 oracle):
+  loss          |d| <= 2e-3 * max(1, loss)
+  logits / enc  relative Frobenius error <= 1e-2, and element-wise atol 3e-2 + rtol 3e-2
+  gradients     relative Frobenius error <= 3e-2 per tensor (fp16 activations-gradients, loss-scaled)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neuspeech1_amd.weights import TINY, WHISPER_BASE, make_lora_state, make_state_dict, synth_batch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def make_engine(dims, dev, lora_r=0, **kw):
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    sd = make_state_dict(dims, 42)
+    lora_sd = make_lora_state(dims, lora_r) if lora_r else None
+    spec = LoraSpec(r=lora_r, alpha=2.0 * lora_r, dropout=0.0) if lora_r else None
+    eng = MegWhisperEngine(dims, sd, lora=spec, lora_sd=lora_sd, train_cfg=TrainCfg(**kw), device=dev)
+    return eng, sd, lora_sd
+
+
+def engine_grads(eng, dims, lora_r):
+    """Engine gradient buffer -> oracle-named fp32 tensors (unscaled)."""
+    s = eng.loss_scale_dev.item()
+    out = {}
+    for nm in ("conv1.0", "conv1.2", "conv2"):
+        out[f"model.encoder.{nm}.weight"] = eng.conv_weight_grad(nm).float().cpu() / s
+        out[f"model.encoder.{nm}.bias"] = eng.gview(f"model.encoder.{nm}.bias").float().cpu() / s
+    if lora_r:
+        d, f, r = dims.d, dims.ffn, lora_r
+        for i in range(dims.enc_layers):
+            p = f"model.encoder.layers.{i}."
+            A = eng.gview(p + "self_attn.qkv.lora_A").view(3, r, d).cpu() / s
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[p + f"self_attn.{nm}.lora_A.weight"] = A[j]
+                out[p + f"self_attn.{nm}.lora_B.weight"] = eng.gview(p + f"self_attn.{nm}.lora_B").view(d, r).cpu() / s
+            for nm, no, ki in (("self_attn.out_proj", d, d), ("fc1", f, d), ("fc2", d, f)):
+                out[p + nm + ".lora_A.weight"] = eng.gview(p + nm + ".lora_A").view(r, ki).cpu() / s
+                out[p + nm + ".lora_B.weight"] = eng.gview(p + nm + ".lora_B").view(no, r).cpu() / s
+    return out
+
+
+@pytest.mark.parametrize("lora_r", [0, 32])
+def test_tiny_forward_backward_vs_oracle(dev, lora_r):
+    from oracle import whisper_meg_oracle as O
+    dims = TINY
+    eng, sd, lora_sd = make_engine(dims, dev, lora_r)
+    x, labels = synth_batch(dims, 3, 77)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, logits = eng.forward(xd, ld, train=True, compute_grad=False)
+    loss_v = loss.item()
+    logits_v = logits.float().cpu()
+    enc_v = eng._b["enc16"].float().cpu().view(3, dims.src_pos, dims.d)
+    o_loss, o_logits, o_enc, o_grads = O.loss_and_grads(sd, lora_sd, x, labels, dims, 2.0 if lora_r else 0.0)
+    assert abs(loss_v - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss_v, o_loss.item())
+    assert rel(enc_v, o_enc) < 1e-2, rel(enc_v, o_enc)
+    assert rel(logits_v, o_logits) < 1e-2, rel(logits_v, o_logits)
+    torch.testing.assert_close(logits_v, o_logits, atol=3e-2, rtol=3e-2)
+    # backward
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    got = engine_grads(eng, dims, lora_r)
+    worst = {}
+    for k, ref in o_grads.items():
+        worst[k] = rel(got[k], ref)
+    bad = {k: v for k, v in worst.items() if not v < 3e-2}
+    assert not bad, f"gradient mismatch: {bad}"
+
+
+def test_tiny_matches_reference_golden(dev):
+    g = np.load(os.path.join(G, "train_tiny.npz"))
+    dims = TINY
+    eng, sd, _ = make_engine(dims, dev, 0)
+    x, labels = synth_batch(dims, int(g["B"]), int(g["seed_d"]))
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, logits = eng.forward(xd, ld, train=True, compute_grad=True)
+    lg = logits.float().cpu().numpy()
+    eng.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"])
+    assert rel(eng._b["enc16"].float().cpu().view(g["enc"].shape), g["enc"]) < 1e-2
+    # dlogits overwrote logits in the training pass; recompute forward-only for the logits check
+    _, logits = eng.forward(xd, ld, train=False)
+    lg = logits.float().cpu().numpy()
+    assert rel(lg, g["logits"]) < 1e-2
+    sure = g["top_margin"] > 0.05
+    assert np.array_equal(lg.argmax(-1)[sure], g["top1_id"][sure])
+    got = engine_grads(eng, dims, 0)
+    for k in ("model.encoder.conv1.0.weight", "model.encoder.conv1.0.bias", "model.encoder.conv1.2.bias",
+              "model.encoder.conv2.bias"):
+        assert rel(got[k], g["grad." + k]) < 3e-2, (k, rel(got[k], g["grad." + k]))
+    for k in ("model.encoder.conv1.2.weight", "model.encoder.conv2.weight"):
+        assert rel(got[k][:48, :48], g["gradblock." + k]) < 3e-2, k
+        assert abs(got[k].double().norm().item() - float(g["gradnorm." + k])) < 3e-2 * float(g["gradnorm." + k])
+
+
+def test_base_shape_matches_reference_golden(dev):
+    """whisper-base dims, 208 channels, T=6000 (BASELINE configs[0]/[1] shape at B=2)."""
+    g = np.load(os.path.join(G, "train_base208.npz"))
+    dims = WHISPER_BASE
+    eng, sd, _ = make_engine(dims, dev, 0)
+    x, labels = synth_batch(dims, int(g["B"]), int(g["seed_d"]))
+    assert np.array_equal(labels, g["labels"])
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    enc = eng._b["enc16"].float().cpu().view(int(g["B"]), dims.src_pos, dims.d).numpy()
+    assert rel(enc[:, ::97, :16], g["enc_slice"]) < 2e-2
+    assert abs(np.sqrt((enc.astype(np.float64) ** 2).sum()) - float(g["enc_l2"])) < 1e-2 * float(g["enc_l2"])
+    got = engine_grads(eng, dims, 0)
+    for k in ("model.encoder.conv1.0.weight", "model.encoder.conv1.2.weight", "model.encoder.conv2.weight",
+              "model.encoder.conv1.0.bias", "model.encoder.conv1.2.bias", "model.encoder.conv2.bias"):
+        n = got[k].double().norm().item()
+        assert abs(n - float(g["gradnorm." + k])) < 4e-2 * float(g["gradnorm." + k]), (k, n, float(g["gradnorm." + k]))
+        assert rel(got[k].reshape(got[k].shape[0], -1)[:8, :8], g["gradslice." + k]) < 6e-2, k
+    _, logits = eng.forward(xd, ld, train=False)
+    lg = logits.float().cpu().numpy()
+    assert rel(lg[:, :, :16], g["logits_slice"]) < 2e-2
+    sure = g["top_margin"] > 0.1
+    assert np.array_equal(lg.argmax(-1)[sure], g["top1_id"][sure])
+
+
+def test_train_steps_reduce_loss_and_match_oracle_update(dev):
+    """3 optimizer steps on one batch: loss falls; first update equals AdamW on the oracle's gradients."""
+    from oracle import whisper_meg_oracle as O
+    dims = TINY
+    eng, sd, lora_sd = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    x, labels = synth_batch(dims, 4, 5)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    p0 = eng.P.clone()
+    losses = [eng.train_step(xd, ld).item() for _ in range(4)]
+    assert eng.step_dev.item() == 4 and eng.found_inf_dev.item() == 0
+    assert losses[-1] < losses[0], losses
+    # one fresh step: compare the parameter delta of conv2.bias with the oracle's AdamW (step 1: delta = -lr*sign(g) ~)
+    eng2, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0, max_grad_norm=0.0)
+    eng2.train_step(xd, ld)
+    _, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, 2.0)
+    gref = og["model.encoder.conv2.bias"]
+    pref, _, _ = O.adamw_reference(torch.from_numpy(sd["model.encoder.conv2.bias"]), gref, torch.zeros_like(gref),
+                                   torch.zeros_like(gref), 1, 1e-3)
+    got = eng2.pview("model.encoder.conv2.bias").cpu()
+    big = gref.abs() > 1e-4 * gref.abs().max()   # step-1 AdamW is ~sign(g): ignore near-zero gradients
+    torch.testing.assert_close(got[big], pref[big], atol=2e-5, rtol=0)

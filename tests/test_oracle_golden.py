@@ -1,0 +1,86 @@
+"""CPU: pin the oracle (oracle/whisper_meg_oracle.py) against golden vectors produced by the reference
+object (stock HF Whisper + the reference's projection_module; tools/make_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neuspeech1_amd.weights import TINY, WHISPER_BASE, make_lora_state, make_state_dict, synth_batch
+from oracle import whisper_meg_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+torch.set_num_threads(8)
+
+
+def test_oracle_matches_reference_tiny_fwd_bwd():
+    g = np.load(os.path.join(G, "train_tiny.npz"))
+    sd = make_state_dict(TINY, int(g["seed_w"]))
+    x, labels = synth_batch(TINY, int(g["B"]), int(g["seed_d"]))
+    assert np.array_equal(labels, g["labels"])
+    loss, logits, enc, grads = O.loss_and_grads(sd, None, x, labels, TINY, 0.0)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    np.testing.assert_allclose(enc.numpy(), g["enc"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-4, rtol=1e-4)
+    for k in O.TRAINABLE_CONV:
+        got = grads[k].numpy()
+        if ("grad." + k) in g:
+            np.testing.assert_allclose(got, g["grad." + k], atol=2e-5, rtol=2e-3)
+        else:
+            np.testing.assert_allclose(got[:48, :48], g["gradblock." + k], atol=2e-5, rtol=2e-3)
+            assert abs(np.sqrt((got.astype(np.float64) ** 2).sum()) - float(g["gradnorm." + k])) < 1e-4 * float(g["gradnorm." + k])
+
+
+def test_oracle_lora_equals_reference_on_merged_weights():
+    g = np.load(os.path.join(G, "lora_merged_tiny.npz"))
+    r, alpha = int(g["r"]), float(g["alpha"])
+    sd = make_state_dict(TINY, 42)
+    lora = make_lora_state(TINY, r)
+    x, labels = synth_batch(TINY, int(g["B"]), 1234)
+    with torch.no_grad():
+        loss, logits, _ = O.forward(O.to_torch(sd), torch.from_numpy(x), TINY, labels=torch.from_numpy(labels),
+                                    lora=O.to_torch(lora), scale=alpha / r)
+    assert abs(loss.item() - float(g["loss"])) < 5e-5
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,ch,B", [("base208", 208, 2)])
+def test_oracle_matches_reference_base_shape(tag, ch, B):
+    g = np.load(os.path.join(G, f"train_{tag}.npz"))
+    dims = WHISPER_BASE
+    sd = make_state_dict(dims, 42)
+    x, labels = synth_batch(dims, B, 1234)
+    loss, logits, enc, grads = O.loss_and_grads(sd, None, x, labels, dims, 0.0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    np.testing.assert_allclose(enc.numpy()[:, ::97, :16], g["enc_slice"], atol=5e-4, rtol=1e-3)
+    np.testing.assert_allclose(logits.numpy()[:, :, :16], g["logits_slice"], atol=2e-3, rtol=1e-3)
+    assert np.array_equal(logits.numpy().argmax(-1)[g["top_margin"] > 1e-3], g["top1_id"][g["top_margin"] > 1e-3])
+    for k in O.TRAINABLE_CONV:
+        gr = grads[k].numpy()
+        n = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(n - float(g["gradnorm." + k])) < 2e-3 * float(g["gradnorm." + k]), k
+
+
+def test_reader_collate_and_matchers():
+    rng = np.random.default_rng(0)
+    for n_ch, name, modal_ch, lo in ((224, "gwilliams", 208, 0), (301, "schoffelen", 273, 28), (100, None, 208, 0)):
+        for n in (700, 6000, 7321):
+            s = rng.standard_normal((n_ch, n))
+            out = O.reader_pad_sample(s, name, modal_ch, 6000)
+            assert out.shape == (modal_ch, 6000) and out.dtype == np.float64
+            m = min(n, 6000)
+            keep = min(n_ch - lo, modal_ch)
+            np.testing.assert_array_equal(out[:keep, :m], s[lo:lo + keep, :m])
+            assert not out[:, m:].any() and not out[keep:].any()
+    feats = [{"input_features": [np.ones((3, 8))], "labels": [7, 1, 2]}, {"input_features": [np.zeros((3, 8))], "labels": [7, 5]}]
+    b = O.collate(feats, pad_id=9, bos_id=7)
+    assert b["input_features"].dtype == torch.float32 and b["input_features"].shape == (2, 3, 8)
+    assert b["labels"].tolist() == [[1, 2], [5, -100]]
+    b = O.collate(feats, pad_id=9, bos_id=3)
+    assert b["labels"].tolist() == [[7, 1, 2], [7, 5, -100]]
+    names = [f"model.encoder.layers.{i}.{m}" for i in range(6) for m in
+             ("self_attn.k_proj", "self_attn.v_proj", "self_attn.q_proj", "self_attn.out_proj", "self_attn_layer_norm",
+              "fc1", "fc2", "final_layer_norm")] + ["model.decoder.layers.0.fc1", "model.encoder.conv1"]
+    got = O.match_modules_string(names, ["model.encoder"], ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"])
+    assert len(got) == 36 and all(n.startswith("model.encoder.layers.") for n in got)
+    assert O.shift_tokens_right(torch.tensor([[5, 6, -100]]), 9, 1).tolist() == [[1, 5, 6]]

@@ -1,0 +1,154 @@
+"""Generate tests/golden/*.npz by running the REFERENCE OBJECT in the build container:
+stock `transformers.WhisperForConditionalGeneration` (eager attention, fp32, CPU) with the
+reference's own `utils/model_utils.projection_module('base', ...)` installed through
+`model.model.encoder.set_input_embeddings` — what /root/reference/evaluation.py:72-86 builds.
+
+Run here only (needs /root/reference):   python tools/make_goldens.py
+The fixtures are data (inputs are regenerated from seeds by neuspeech1_amd.weights; outputs are
+stored); no reference source travels.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neuspeech1_amd.weights import TINY, WHISPER_BASE, WhisperDims, make_lora_state, make_state_dict, synth_batch  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_projection_module():
+    spec = importlib.util.spec_from_file_location("ref_model_utils", os.path.join(REF, "utils", "model_utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.projection_module
+
+
+def build_hf(dims: WhisperDims, sd_np):
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(vocab_size=dims.vocab, num_mel_bins=80, d_model=dims.d, encoder_layers=dims.enc_layers,
+                        decoder_layers=dims.dec_layers, encoder_attention_heads=dims.heads,
+                        decoder_attention_heads=dims.heads, encoder_ffn_dim=dims.ffn, decoder_ffn_dim=dims.ffn,
+                        max_source_positions=dims.src_pos, max_target_positions=dims.tgt_pos,
+                        pad_token_id=dims.pad_id, bos_token_id=dims.bos_id, eos_token_id=dims.eos_id,
+                        decoder_start_token_id=dims.start_id, attn_implementation="eager",
+                        suppress_tokens=[], begin_suppress_tokens=[])
+    model = WhisperForConditionalGeneration(cfg)
+    conv1 = ref_projection_module()(config_name="base", meg_ch=dims.ch, d_model=model.model.encoder.conv2.in_channels)
+    model.model.encoder.set_input_embeddings(conv1)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("proj_out" in m for m in missing), missing
+    model.eval()
+    return model
+
+
+TRAINABLE = ("model.encoder.conv1.0.weight", "model.encoder.conv1.0.bias", "model.encoder.conv1.2.weight",
+             "model.encoder.conv1.2.bias", "model.encoder.conv2.weight", "model.encoder.conv2.bias")
+
+
+def train_golden(dims, tag, B, seed_w=42, seed_d=1234, full=True):
+    sd_np = make_state_dict(dims, seed_w)
+    model = build_hf(dims, sd_np)
+    x, labels = synth_batch(dims, B, seed_d)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    named = dict(model.named_parameters())
+    for k in TRAINABLE:
+        named[k].requires_grad_(True)
+    out = model(input_features=torch.from_numpy(x), labels=torch.from_numpy(labels))
+    out.loss.backward()
+    enc = out.encoder_last_hidden_state.detach().numpy()
+    logits = out.logits.detach().numpy()
+    g = {"loss": np.float32(out.loss.item()), "B": B, "seed_w": seed_w, "seed_d": seed_d, "labels": labels}
+    top2 = np.sort(logits, -1)[..., -2:]
+    g["top1_id"] = logits.argmax(-1).astype(np.int32)
+    g["top_margin"] = (top2[..., 1] - top2[..., 0]).astype(np.float32)
+    if full:
+        g["enc"] = enc.astype(np.float32)
+        g["logits"] = logits.astype(np.float32)
+        for k in TRAINABLE:
+            gr = named[k].grad.numpy().astype(np.float32)
+            if gr.size > 100_000:      # keep fixtures small: leading block + Frobenius norm
+                g["gradblock." + k] = gr[:48, :48].copy()
+                g["gradnorm." + k] = np.float64(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+            else:
+                g["grad." + k] = gr
+    else:
+        g["enc_slice"] = enc[:, ::97, :16].astype(np.float32)
+        g["logits_slice"] = logits[:, :, :16].astype(np.float32)
+        g["enc_sum"] = np.float64(enc.astype(np.float64).sum())
+        g["enc_l2"] = np.float64(np.sqrt((enc.astype(np.float64) ** 2).sum()))
+        for k in TRAINABLE:
+            gr = named[k].grad.numpy()
+            g["gradnorm." + k] = np.float64(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+            g["gradslice." + k] = gr.reshape(gr.shape[0], -1)[:8, :8].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"train_{tag}.npz"), **g)
+    print(f"train_{tag}: loss {g['loss']:.6f}")
+    return sd_np, x, labels
+
+
+def lora_golden(dims, tag, B, r=32, alpha=64.0):
+    """LoRA is pinned through merged-weight equivalence: the reference object run on W + (alpha/r) B A."""
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle.whisper_meg_oracle import lora_merge
+    sd_np = make_state_dict(dims, 42)
+    lora_np = make_lora_state(dims, r)
+    merged = lora_merge(sd_np, lora_np, alpha / r)
+    model = build_hf(dims, merged)
+    x, labels = synth_batch(dims, B, 1234)
+    with torch.no_grad():
+        out = model(input_features=torch.from_numpy(x), labels=torch.from_numpy(labels))
+    np.savez_compressed(os.path.join(OUT, f"lora_merged_{tag}.npz"), loss=np.float32(out.loss.item()),
+                        logits=out.logits.numpy().astype(np.float32), r=r, alpha=alpha, B=B)
+    print(f"lora_merged_{tag}: loss {out.loss.item():.6f}")
+
+
+def decode_golden(dims, tag, B, new_tokens):
+    import transformers
+    sd_np = make_state_dict(dims, 42)
+    model = build_hf(dims, sd_np)
+    x, labels = synth_batch(dims, B, 1234)
+    prompt = torch.from_numpy(labels[:, :4].copy())
+    feats = torch.from_numpy(x)
+    g = {"B": B, "new_tokens": new_tokens, "prompt": prompt.numpy()}
+    common = dict(do_sample=False, max_new_tokens=new_tokens, decoder_input_ids=prompt, suppress_tokens=None,
+                  begin_suppress_tokens=None, pad_token_id=dims.pad_id, eos_token_id=dims.eos_id,
+                  return_dict_in_generate=True, output_scores=True)
+    gen = transformers.GenerationMixin.generate
+    with torch.no_grad():
+        o = gen(model, feats, num_beams=1, **common)
+        g["greedy"] = o.sequences.numpy()
+        g["greedy_step0_scores"] = o.scores[0].numpy()[:, :64].astype(np.float32)
+        o = gen(model, feats, num_beams=1, repetition_penalty=5.0, no_repeat_ngram_size=2, **common)
+        g["greedy_rp"] = o.sequences.numpy()
+        o = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, **common)
+        g["beam5_rp"] = o.sequences.numpy()
+        g["beam5_rp_scores"] = o.sequences_scores.numpy().astype(np.float32)
+        o = gen(model, feats, num_beams=5, **common)
+        g["beam5"] = o.sequences.numpy()
+        g["beam5_scores"] = o.sequences_scores.numpy().astype(np.float32)
+        # EOS-friendly variant: bias the EOS row of the tied embedding so hypotheses finish early
+    np.savez_compressed(os.path.join(OUT, f"decode_{tag}.npz"), **g)
+    print(f"decode_{tag}: greedy tail {g['greedy'][:, -4:].tolist()}")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    what = sys.argv[1:] or ["train", "lora", "decode"]
+    if "train" in what:
+        train_golden(TINY, "tiny", B=2, full=True)
+        train_golden(WHISPER_BASE, "base208", B=2, full=False)
+        train_golden(WhisperDims(ch=273), "base273", B=1, full=False)
+    if "lora" in what:
+        lora_golden(TINY, "tiny", B=2)
+    if "decode" in what:
+        decode_golden(TINY, "tiny", B=3, new_tokens=24)
