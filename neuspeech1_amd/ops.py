@@ -35,6 +35,7 @@ def rowmap(ld: int, seg_rows: int = 0, seg_stride: int = 0) -> RowMap:
 
 
 _ZERO_MAP = RowMap(0, 0, 0)
+GEMM_PROFILE = None   # set to a list by bench.py to time every GEMM launch with HIP events
 
 
 def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
@@ -56,7 +57,16 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     d.C32, d.ldc32 = ptr(C32), ldc32
     d.flags, d.splits = flags, splits
     d.drop_p, d.drop_seed, d.alpha = drop_p, drop_seed, alpha
+    if GEMM_PROFILE is None:
+        L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
+        return
+    # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
+    kind = "tn" if flags & NS_GEMM_TN else ("nt32" if N <= 96 else "nt128")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
+    e1.record(torch.cuda.current_stream())
+    GEMM_PROFILE.append((kind, 2.0 * M * N * (K + K2), e0, e1))
 
 
 def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5):
