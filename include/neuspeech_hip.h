@@ -113,6 +113,8 @@ typedef struct {
 } ns_gemm_desc;
 
 int ns_gemm(const ns_gemm_desc* d, void* stream);
+/* A/B knob for benchmarks: 1 (default) = LDS-DMA ring kernel for the wide NT form, 0 = register-staged kernel */
+void ns_debug_set_ring(int on);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the fp32 residual stream (eps 1e-5, affine), one row = d

@@ -412,6 +412,10 @@ void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
+static int g_use_ring = 1;
+extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
+
 extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   NS_CHECK_ARG(d != nullptr, "ns_gemm: null descriptor");
   NS_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "ns_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -458,6 +462,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
   } else if (skinny) {
     if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
+  } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
+    ns_gemm_ring_launch(d, st);
   } else {
     if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);
   }

@@ -1,0 +1,191 @@
+// ns_gemm NT hot path: 128x128 tile, K streamed through a 4-stage LDS ring of 32-deep slices filled
+// by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), three slices in flight
+// behind a COUNTED s_waitcnt vmcnt(N) and ONE raw s_barrier per slice (cdna guide §5 "Pipelining
+// across barriers").  64 KiB of LDS per block -> 2 blocks per CU, so one block's epilogue overlaps
+// the other's main loop; the fp32 epilogue tile reuses the ring.
+//
+// LDS slice image: [128 rows][32 k] fp16 = 64-B rows, lane-linear per DMA instruction (16 rows x 64 B
+// = 1 KiB).  The 16-B chunk index is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the
+// ds_read_b128 address (never on the LDS destination), which makes the fragment reads (lane = row,
+// same chunk) conflict-free across the 16-lane ds_read_b128 groups.
+#include "ns_gemm_epi.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKS = 32, NST = 4, NTH = 256;
+constexpr int HALF_BYTES = BM * BKS * 2;       // 8 KiB: one operand slice
+constexpr int STAGE_BYTES = 2 * HALF_BYTES;    // 16 KiB
+
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int wgid;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- DMA source pointers: this wave fills rows [32*wave, 32*wave+32) of both operand slices with
+  // two 1-KiB instructions each; lane -> (row = 16*j + lane/4, LDS chunk' = lane%4) <- global chunk' ^ swz(row)
+  const half_t* a_src[2];
+  const half_t* b_src[2];
+  const half_t* a2_src[2] = {nullptr, nullptr};
+  const half_t* b2_src[2] = {nullptr, nullptr};
+  int my_chunk[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = 16 * (wave * 2 + jj) + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    my_chunk[jj] = chunk;
+    a_src[jj] = (const half_t*)p.A + ns_rm_off64(p.am, min(m0 + row, p.M - 1)) + chunk * 8;
+    b_src[jj] = (const half_t*)p.B + (long long)min(n0 + row, p.N - 1) * p.bm.ld + chunk * 8;
+  }
+  if (p.K2 > 0) {
+    const int goff = p.a2_ngroup > 0 ? (n0 / p.a2_ngroup) * p.K2 : 0;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int row = 16 * (wave * 2 + jj) + (lane >> 2);
+      a2_src[jj] = (const half_t*)p.A2 + ns_rm_off64(p.am2, min(m0 + row, p.M - 1)) + goff + my_chunk[jj] * 8;
+      b2_src[jj] = (const half_t*)p.B2 + (long long)min(n0 + row, p.N - 1) * p.ldb2 + my_chunk[jj] * 8;
+    }
+  }
+
+  const int steps1 = (p.K + BKS - 1) / BKS;
+  const int steps2 = (p.K2 + BKS - 1) / BKS;
+  const int nsteps = steps1 + steps2;
+  const bool seg2_first = DROP && steps2 > 0;   // dgrad with LoRA dropout: (A2,B2) first, mask, then the main product
+
+  auto step_info = [&](int s, bool& is2, int& k0, int& klen) __attribute__((always_inline)) {
+    if (seg2_first) { is2 = s < steps2; k0 = (is2 ? s : s - steps2) * BKS; }
+    else { is2 = s >= steps1; k0 = (is2 ? s - steps1 : s) * BKS; }
+    klen = (is2 ? p.K2 : p.K) - k0;
+    klen = klen > BKS ? BKS : klen;
+  };
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    bool is2; int k0, klen; step_info(s, is2, k0, klen);
+    char* const dst = smem + (s % NST) * STAGE_BYTES + (wave * 2) * 1024;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      // a chunk beyond the valid K range is redirected to chunk 0 (valid memory, never consumed)
+      const int ko = (my_chunk[jj] * 8 < klen) ? k0 : k0 - my_chunk[jj] * 8;
+      glds16((is2 ? a2_src[jj] : a_src[jj]) + ko, dst + jj * 1024);
+      glds16((is2 ? b2_src[jj] : b_src[jj]) + ko, dst + HALF_BYTES + jj * 1024);
+    }
+  };
+  auto compute = [&](int buf, int klen) __attribute__((always_inline)) {
+    const char* as = smem + buf * STAGE_BYTES;
+    const char* bs = as + HALF_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s * 16 < klen) {
+        half8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *(const half8*)(as + lds_off32(wm * 64 + i * 32 + lr, 2 * s + lh));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *(const half8*)(bs + lds_off32(wn * 64 + j * 32 + lr, 2 * s + lh));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: NST-1 slices in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nsteps) issue(s);
+
+  for (int s = 0; s < nsteps; ++s) {
+    // slices s+1 .. min(s+NST-2, nsteps-1) may stay in flight (4 DMA instructions per slice per wave)
+    const int ahead = min(NST - 2, nsteps - 1 - s);
+    if (ahead >= 2) wait_vmcnt<8>();
+    else if (ahead == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // every wave's slice-s DMA has landed; every wave finished slice s-1
+    asm volatile("" ::: "memory");
+    if (s + NST - 1 < nsteps) issue(s + NST - 1);   // refills the buffer slice s-1 lived in
+    bool is2; int k0, klen; step_info(s, is2, k0, klen);
+    compute(s % NST, klen);
+    if (DROP && seg2_first && s == steps2 - 1) {
+      const float drop_inv = 1.f / (1.f - p.drop_p);
+      const uint32_t drop_thr = (uint32_t)(p.drop_p * 4294967296.f);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t row = (uint32_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            const uint32_t col = (uint32_t)(n0 + wn * 64 + j * 32 + lr);
+            acc[i][j][r] = ns_hash3(p.drop_seed, row, col) >= drop_thr ? acc[i][j][r] * drop_inv : 0.f;
+          }
+    }
+  }
+
+  // ---- epilogue through LDS (the ring is dead: no DMA outstanding, wait for the last readers)
+  __syncthreads();
+  float* const ct = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        ct[row * BN + wn * 64 + j * 32 + lr] = acc[i][j][r];
+      }
+  __syncthreads();
+  ns_nt_epilogue<BM, BN, NTH>(p, ct, m0, n0, tid);
+}
+
+}  // namespace
+
+// called by ns_gemm() for NT descriptors with N > 96 and no A-operand dropout (arguments already validated)
+int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
+  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  const size_t lds = NST * STAGE_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring_kernel<true>, dim3(tiles), dim3(NTH), lds, st, *d);
+  else hipLaunchKernelGGL(ns_gemm_ring_kernel<false>, dim3(tiles), dim3(NTH), lds, st, *d);
+  return 0;
+}

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ns_version": (C.c_int, []),
     "ns_last_error": (C.c_char_p, []),
     "ns_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "ns_debug_set_ring": (None, [C.c_int]),
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
