@@ -208,6 +208,61 @@ int ns_adamw_step(float* p, const float* g, float* m, float* v, size_t n, const 
                   int* step_dev, const float* norm2_dev, const int* found_inf_dev, float* loss_scale_dev,
                   int* growth_tracker_dev, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Decode loop (evaluation.py:369-386 -> HF GenerationMixin greedy / beam search).
+ * ---------------------------------------------------------------------- */
+/* One new query per row against a K/V cache, head_dim 64.  Rows are grouped: group g = rows
+ * [g*nq, (g+1)*nq) share ONE K/V stream (cross-attention: the encoder K/V of a sequence is read once
+ * for all its beams; key row = g*kv_group_stride + j).  With `anc` (nq must be 1) key j of row r lives at
+ * row j*kv_pos_stride + anc[r*anc_ld + j] (self-attention cache laid out [position][slot], beams reordered by
+ * rewriting the small int32 ancestry table instead of the K/V tensors, cf. utils/load_model.py:1353-1360).
+ * kv_len_dev (optional) overrides Lk from device memory. */
+typedef struct {
+  const void *Q, *K, *V; void* O;
+  const int32_t* anc; const int32_t* kv_len_dev;
+  int32_t groups, nq, H, Lk, Lk_max, head_dim;
+  int32_t ldq, ldk, ldv, ldo, anc_ld;
+  int64_t kv_group_stride, kv_pos_stride;
+} ns_attn_decode_desc;
+int ns_attn_decode(const ns_attn_decode_desc* d, void* stream);
+
+/* Last-position logits (fp16, rows x ldv) -> processed fp32 scores (rows x V):
+ * [log_softmax] -> repetition penalty (s<0 ? s*p : s/p on tokens already in ids[row][0:cur_len]) ->
+ * no-repeat-ngram (-inf) -> suppress / begin-suppress lists (-inf) -> + beam_scores[row].
+ * HF:generation/logits_process.py:306-414, :1073-1141, :1816-1906; order as HF:generation/utils.py:3388-3407. */
+typedef struct {
+  const void* logits16; float* scores32; const int64_t* ids; const float* beam_scores;
+  const int32_t* suppress; const int32_t* begin_suppress; const int32_t* cur_len_dev;
+  int32_t rows, V, ldv, ids_ld, cur_len, begin_index;
+  int32_t n_suppress, n_begin_suppress, no_repeat_ngram, log_softmax;
+  float repetition_penalty;
+} ns_logits_proc_desc;
+int ns_logits_process(const ns_logits_proc_desc* d, void* stream);
+
+/* top-k (k <= 16) of each group of n contiguous floats, ordered (value desc, index asc) */
+int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* stream);
+
+/* HF beam-search bookkeeping for one step (HF:generation/utils.py:3077-3204, :3008-3075): from the top-2*beams
+ * candidates pick the next running beams, merge just-finished hypotheses (score / (cur+1-prompt)^lp) into the
+ * finished set, update the per-row early-stop flag; ORs into *any_open / *any_continuation (caller zeroes). */
+typedef struct {
+  const float* top_vals; const int32_t* top_idx;
+  const int64_t* run_seqs_in; int64_t* run_seqs_out; float* run_scores_out;
+  const int64_t* fin_seqs_in; int64_t* fin_seqs_out;
+  const float* fin_scores_in; float* fin_scores_out;
+  const uint8_t* fin_done_in; uint8_t* fin_done_out;
+  uint8_t* open; int32_t* parent_out; int64_t* next_tok_out;
+  int32_t* any_open; int32_t* any_continuation; const int32_t* cur_len_dev;
+  int32_t batch, num_beams, V, max_len, cur_len, prompt_len, eos_id;
+  float length_penalty;
+} ns_beam_desc;
+int ns_beam_update(const ns_beam_desc* d, void* stream);
+int ns_anc_update(const int* anc_in, int* anc_out, const int* parent, int rows, int ld, int cur, const int* cur_dev,
+                  void* stream);
+/* greedy: argmax of processed scores, finished rows emit pad (HF:generation/utils.py:2897-2960) */
+int ns_greedy_update(const float* scores, int rows, int V, int64_t* seqs, int ld, int cur, const int* cur_dev, int eos,
+                     int pad, unsigned char* done, int* any_open, int64_t* next_tok, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

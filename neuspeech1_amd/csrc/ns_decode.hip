@@ -1,0 +1,415 @@
+// Decode-time kernels of the generate loop (HBM-bound byte work, no MFMA):
+//   ns_attn_decode     one new query per row against a K/V cache (self: beam ancestry indirection,
+//                      cross: the encoder K/V of a sequence is read ONCE for all its beams)
+//   ns_logits_process  log_softmax + repetition penalty + no-repeat-ngram + suppress lists (+ beam score)
+//   ns_topk_groups     top-k over each sequence's (beams x V) accumulated scores
+//   ns_beam_update     HF beam bookkeeping (running beams, finished hypotheses, early-stop heuristic)
+//   ns_greedy_update   argmax + EOS/pad bookkeeping
+// Replaces, for the path evaluation.py:369-386 drives: HF:generation/utils.py:2783-2975 (greedy), :3077-3545
+// (beam search), HF:generation/logits_process.py:306-414, :1073-1141, :1816-1906 and the cache reorder
+// utils/load_model.py:1353-1360 (here: an int32 ancestry table instead of re-gathering K/V tensors).
+#include "ns_common.h"
+
+namespace {
+
+constexpr int MAXQ = 8;       // queries (beams) sharing one K/V stream
+constexpr int D = 64;
+
+// ---------------------------------------------------------------------------------------------- attention
+// grid (groups, H); group = nq consecutive rows.  8-lane subgroups own one key at a time (lane8 = 8 dims).
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const sc = (float*)smem;                       // [NQ][Lk_pad]
+  const int Lk = p.kv_len_dev ? *p.kv_len_dev : p.Lk;
+  const int lkp = (p.Lk_max + 3) & ~3;
+  float* const red = sc + NQ * lkp;                     // [4][NQ][64]
+  __shared__ float stat[MAXQ][4];
+  const int tid = threadIdx.x, sg = tid >> 3, l8 = tid & 7, wave = tid >> 6, lane = tid & 63;
+  const int grp = blockIdx.x, h = blockIdx.y;
+  const half_t* Kb = (const half_t*)p.K + h * D + l8 * 8;
+  const half_t* Vb = (const half_t*)p.V + h * D + l8 * 8;
+  const int* anc = p.anc ? p.anc + (long long)grp * p.anc_ld : nullptr;   // only with NQ == 1
+
+  float q[NQ][8];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const half8 qv = *(const half8*)((const half_t*)p.Q + (long long)(grp * NQ + qi) * p.ldq + h * D + l8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[qi][e] = (float)qv[e];
+  }
+  auto krow = [&](int j) -> long long {
+    return anc ? (long long)j * p.kv_pos_stride + anc[j] : (long long)grp * p.kv_group_stride + j;
+  };
+  // ---- scores
+  for (int j = sg; j < Lk; j += 32) {
+    const half8 kv = *(const half8*)(Kb + krow(j) * p.ldk);
+    float kf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kf[e] = (float)kv[e];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += q[qi][e] * kf[e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (l8 == 0) sc[qi * lkp + j] = s;
+    }
+  }
+  __syncthreads();
+  // ---- softmax statistics (one wave per query, round-robin)
+  for (int qi = wave; qi < NQ; qi += 4) {
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, sc[qi * lkp + j]);
+    m = ns_wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+      const float e = __expf(sc[qi * lkp + j] - m);
+      sc[qi * lkp + j] = e;
+      s += e;
+    }
+    s = ns_wave_sum(s);
+    if (lane == 0) stat[qi][0] = 1.f / s;
+  }
+  __syncthreads();
+  // ---- O = P V
+  float acc[NQ][8];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
+  for (int j = sg; j < Lk; j += 32) {
+    const half8 vv = *(const half8*)(Vb + krow(j) * p.ldv);
+    float vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vf[e] = (float)vv[e];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      const float pj = sc[qi * lkp + j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[qi][e] += pj * vf[e];
+    }
+  }
+  // reduce over the 8 subgroups of the wave, then over the 4 waves through LDS
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[qi][e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[qi][e] = v;
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(wave * NQ + qi) * 64 + l8 * 8 + e] = acc[qi][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < NQ * 64; i += 256) {
+    const int qi = i >> 6, dd = i & 63;
+    const float v = red[(0 * NQ + qi) * 64 + dd] + red[(1 * NQ + qi) * 64 + dd] + red[(2 * NQ + qi) * 64 + dd] +
+                    red[(3 * NQ + qi) * 64 + dd];
+    ((half_t*)p.O)[(long long)(grp * NQ + qi) * p.ldo + h * D + dd] = (half_t)(v * stat[qi][0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- processors
+__device__ __forceinline__ float blk_reduce(float v, bool is_max, float* sh) {
+  v = is_max ? ns_wave_max(v) : ns_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void logits_process_kernel(const ns_logits_proc_desc p) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const half_t* lg = (const half_t*)p.logits16 + (long long)row * p.ldv;
+  float* out = p.scores32 + (long long)row * p.V;
+  const int64_t* ids = p.ids + (long long)row * p.ids_ld;
+  const int cur = p.cur_len_dev ? *p.cur_len_dev : p.cur_len;
+  float lse = 0.f;
+  if (p.log_softmax) {
+    float mx = -INFINITY;
+    for (int c = tid; c < p.V; c += 256) mx = fmaxf(mx, (float)lg[c]);
+    mx = blk_reduce(mx, true, sh);
+    float se = 0.f;
+    for (int c = tid; c < p.V; c += 256) se += __expf((float)lg[c] - mx);
+    se = blk_reduce(se, false, sh);
+    lse = mx + __logf(se);
+  }
+  for (int c = tid; c < p.V; c += 256) out[c] = (float)lg[c] - lse;
+  __syncthreads();
+  if (p.repetition_penalty != 1.f) {
+    // every occurrence recomputes from the ORIGINAL value, so duplicates write the same number
+    for (int t = tid; t < cur; t += 256) {
+      const int64_t tok = ids[t];
+      if (tok >= 0 && tok < p.V) {
+        const float b = (float)lg[tok] - lse;
+        out[tok] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+      }
+    }
+    __syncthreads();
+  }
+  const int n = p.no_repeat_ngram;
+  if (n > 0 && cur + 1 >= n) {
+    for (int s = tid; s + n - 1 < cur; s += 256) {
+      bool match = true;
+      for (int e = 0; e < n - 1; ++e) match = match && (ids[s + e] == ids[cur - (n - 1) + e]);
+      if (match) {
+        const int64_t banned = ids[s + n - 1];
+        if (banned >= 0 && banned < p.V) out[banned] = -INFINITY;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < p.n_suppress; i += 256) out[p.suppress[i]] = -INFINITY;
+  if (cur == p.begin_index)
+    for (int i = tid; i < p.n_begin_suppress; i += 256) out[p.begin_suppress[i]] = -INFINITY;
+  if (p.beam_scores) {
+    __syncthreads();
+    const float bs = p.beam_scores[row];
+    for (int c = tid; c < p.V; c += 256) out[c] += bs;
+  }
+}
+
+// top-k of n contiguous floats per group; order = (value desc, index asc); k <= 16
+__global__ __launch_bounds__(256) void topk_groups_kernel(const float* __restrict__ x, long long n, int k,
+                                                          float* __restrict__ vals, int* __restrict__ idx) {
+  __shared__ float shv[4];
+  __shared__ int shi[4];
+  const float* xr = x + (long long)blockIdx.x * n;
+  float pv = INFINITY;
+  int pi = -1;
+  for (int t = 0; t < k; ++t) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+      const float v = xr[i];
+      const bool after = (v < pv) || (v == pv && (int)i > pi);
+      if (after && (v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = bv; shi[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    bv = shv[0]; bi = shi[0];
+    for (int w = 1; w < 4; ++w)
+      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    if (threadIdx.x == 0) { vals[blockIdx.x * k + t] = bv; idx[blockIdx.x * k + t] = bi; }
+    pv = bv; pi = bi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- beam bookkeeping
+__global__ __launch_bounds__(256) void beam_update_kernel(const ns_beam_desc p) {
+  const int b = blockIdx.x, nb = p.num_beams, K2 = 2 * nb, ML = p.max_len;
+  const int cur = p.cur_len_dev ? *p.cur_len_dev : p.cur_len;
+  __shared__ int run_src[MAXQ], run_tok[MAXQ], fin_src[MAXQ], c_beam[2 * MAXQ], c_tok[2 * MAXQ];
+  __shared__ float run_sc[MAXQ], fin_sc[MAXQ];
+  __shared__ unsigned char fin_dn[MAXQ], c_hit[2 * MAXQ];
+  const float* tv = p.top_vals + (long long)b * K2;
+  const int* ti = p.top_idx + (long long)b * K2;
+  if (threadIdx.x == 0) {
+    const bool open = p.open[b] != 0;
+    const float lenf = powf((float)(cur + 1 - p.prompt_len), p.length_penalty);
+    float runc[2 * MAXQ], finc[3 * MAXQ];
+    unsigned char done_m[3 * MAXQ];
+    bool all_hit = true;
+    for (int c = 0; c < K2; ++c) {
+      c_beam[c] = ti[c] / p.V;
+      c_tok[c] = ti[c] - c_beam[c] * p.V;
+      const bool hit = (c_tok[c] == p.eos_id) || (cur + 1 >= ML);
+      c_hit[c] = hit;
+      all_hit = all_hit && hit;
+      runc[c] = tv[c] + (hit ? -1.0e9f : 0.f);
+      const bool just = hit && c < nb;
+      float f = tv[c] / lenf;
+      if (!open) f += -1.0e9f;
+      if (!just) f += -1.0e9f;
+      finc[nb + c] = f;
+      done_m[nb + c] = just;
+    }
+    for (int i = 0; i < nb; ++i) { finc[i] = p.fin_scores_in[b * nb + i]; done_m[i] = p.fin_done_in[b * nb + i]; }
+    // next running beams: best nb of runc (value desc, index asc)
+    unsigned used = 0;
+    for (int r = 0; r < nb; ++r) {
+      int best = -1;
+      for (int c = 0; c < K2; ++c)
+        if (!(used >> c & 1) && (best < 0 || runc[c] > runc[best])) best = c;
+      used |= 1u << best;
+      run_src[r] = best; run_tok[r] = c_tok[best]; run_sc[r] = runc[best];
+    }
+    // finished set: best nb of the merged 3nb list
+    unsigned usedf = 0;
+    for (int r = 0; r < nb; ++r) {
+      int best = -1;
+      for (int c = 0; c < 3 * nb; ++c)
+        if (!(usedf >> c & 1) && (best < 0 || finc[c] > finc[best])) best = c;
+      usedf |= 1u << best;
+      fin_src[r] = best; fin_sc[r] = finc[best]; fin_dn[r] = done_m[best];
+    }
+    // early-stop heuristic at the new length
+    const float best_run = run_sc[0] / powf((float)(cur + 1 - p.prompt_len), p.length_penalty);
+    bool any_empty = false;
+    float mn = INFINITY;
+    for (int r = 0; r < nb; ++r) { any_empty = any_empty || !fin_dn[r]; mn = fminf(mn, fin_sc[r]); }
+    const bool still = open && (any_empty || best_run > mn);
+    p.open[b] = still;
+    if (still) atomicOr(p.any_open, 1);
+    if (!all_hit) atomicOr(p.any_continuation, 1);
+  }
+  __syncthreads();
+  for (int r = 0; r < nb; ++r) {
+    const int64_t* src = p.run_seqs_in + ((long long)b * nb + c_beam[run_src[r]]) * ML;
+    int64_t* dst = p.run_seqs_out + ((long long)b * nb + r) * ML;
+    for (int t = threadIdx.x; t < ML; t += 256) dst[t] = (t == cur) ? (int64_t)run_tok[r] : src[t];
+    const int fs = fin_src[r];
+    int64_t* fdst = p.fin_seqs_out + ((long long)b * nb + r) * ML;
+    if (fs < nb) {
+      const int64_t* fsrc = p.fin_seqs_in + ((long long)b * nb + fs) * ML;
+      for (int t = threadIdx.x; t < ML; t += 256) fdst[t] = fsrc[t];
+    } else {
+      const int c = fs - nb;
+      const int64_t* fsrc = p.run_seqs_in + ((long long)b * nb + c_beam[c]) * ML;
+      for (int t = threadIdx.x; t < ML; t += 256) fdst[t] = (t == cur) ? (int64_t)c_tok[c] : fsrc[t];
+    }
+  }
+  if (threadIdx.x < nb) {
+    const int r = threadIdx.x;
+    p.run_scores_out[b * nb + r] = run_sc[r];
+    p.parent_out[b * nb + r] = b * nb + c_beam[run_src[r]];   // flat row index of the parent beam
+    p.next_tok_out[b * nb + r] = run_tok[r];
+    p.fin_scores_out[b * nb + r] = fin_sc[r];
+    p.fin_done_out[b * nb + r] = fin_dn[r];
+  }
+}
+
+// ancestry reorder: anc_out[row][0..cur) = anc_in[parent[row]][0..cur); anc_out[row][cur] = row
+__global__ void anc_update_kernel(const int* __restrict__ anc_in, int* __restrict__ anc_out, const int* __restrict__ parent,
+                                  int rows, int ld, int cur, const int* cur_dev) {
+  const int row = blockIdx.x;
+  const int c = cur_dev ? *cur_dev : cur;
+  const int par = parent ? parent[row] : row;
+  for (int t = threadIdx.x; t < c; t += blockDim.x) anc_out[(long long)row * ld + t] = anc_in[(long long)par * ld + t];
+  if (threadIdx.x == 0) anc_out[(long long)row * ld + c] = row;
+}
+
+__global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restrict__ scores, int V, int64_t* __restrict__ seqs,
+                                                            int ld, int cur, const int* cur_dev, int eos, int pad,
+                                                            unsigned char* __restrict__ done, int* __restrict__ any_open,
+                                                            int64_t* __restrict__ next_tok) {
+  __shared__ float shv[4];
+  __shared__ int shi[4];
+  const int row = blockIdx.x;
+  const float* s = scores + (long long)row * V;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float v = s[c];
+    if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = bv; shi[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    const int c = cur_dev ? *cur_dev : cur;
+    int tok = done[row] ? pad : bi;
+    seqs[(long long)row * ld + c] = tok;
+    next_tok[row] = tok;
+    const bool d = done[row] || tok == eos;
+    done[row] = d;
+    if (!d) atomicOr(any_open, 1);
+  }
+}
+
+}  // namespace
+
+extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
+  NS_CHECK_ARG(d && d->Q && d->K && d->V && d->O, "ns_attn_decode: null pointer");
+  NS_CHECK_ARG(d->head_dim == 64, "ns_attn_decode: head_dim must be 64");
+  NS_CHECK_ARG(d->nq >= 1 && d->nq <= MAXQ && d->groups > 0 && d->H > 0 && d->Lk > 0 && d->Lk_max >= d->Lk,
+               "ns_attn_decode: bad shape nq=%d groups=%d Lk=%d Lk_max=%d", d->nq, d->groups, d->Lk, d->Lk_max);
+  NS_CHECK_ARG(!d->anc || d->nq == 1, "ns_attn_decode: ancestry indirection needs nq == 1");
+  NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0, "ns_attn_decode: strides must be multiples of 8");
+  const int lkp = (d->Lk_max + 3) & ~3;
+  const size_t lds = ((size_t)d->nq * lkp + 4 * d->nq * 64) * sizeof(float);
+  NS_CHECK_ARG(lds <= 150 * 1024, "ns_attn_decode: Lk_max too large for LDS");
+  dim3 grid(d->groups, d->H);
+  hipStream_t st = (hipStream_t)stream;
+#define NS_AD(NQ_)                                                                                                \
+  case NQ_: {                                                                                                     \
+    static bool attr = false;                                                                                     \
+    if (!attr) { hipFuncSetAttribute((const void*)attn_decode_kernel<NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; } \
+    hipLaunchKernelGGL(attn_decode_kernel<NQ_>, grid, dim3(256), lds, st, *d);                                     \
+  } break;
+  switch (d->nq) {
+    NS_AD(1) NS_AD(2) NS_AD(3) NS_AD(4) NS_AD(5) NS_AD(6) NS_AD(7) NS_AD(8)
+  }
+#undef NS_AD
+  NS_CHECK_LAUNCH("ns_attn_decode");
+  return NS_OK;
+}
+
+extern "C" int ns_logits_process(const ns_logits_proc_desc* d, void* stream) {
+  NS_CHECK_ARG(d && d->logits16 && d->scores32 && d->ids, "ns_logits_process: null pointer");
+  NS_CHECK_ARG(d->rows > 0 && d->V > 0 && d->ldv >= d->V && d->no_repeat_ngram >= 0, "ns_logits_process: bad shape");
+  NS_CHECK_ARG(d->repetition_penalty > 0.f, "ns_logits_process: repetition_penalty must be > 0");
+  hipLaunchKernelGGL(logits_process_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)stream, *d);
+  NS_CHECK_LAUNCH("ns_logits_process");
+  return NS_OK;
+}
+
+extern "C" int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* stream) {
+  NS_CHECK_ARG(x && vals && idx && groups > 0 && n > 0 && k > 0 && k <= 16 && n < 0x7fffffffLL, "ns_topk_groups: bad arguments");
+  hipLaunchKernelGGL(topk_groups_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, n, k, vals, idx);
+  NS_CHECK_LAUNCH("ns_topk_groups");
+  return NS_OK;
+}
+
+extern "C" int ns_beam_update(const ns_beam_desc* d, void* stream) {
+  NS_CHECK_ARG(d && d->top_vals && d->top_idx && d->run_seqs_in && d->run_seqs_out && d->fin_seqs_in && d->fin_seqs_out &&
+                   d->open && d->any_open && d->any_continuation, "ns_beam_update: null pointer");
+  NS_CHECK_ARG(d->num_beams >= 1 && d->num_beams <= MAXQ && d->batch > 0 && d->max_len > 0, "ns_beam_update: bad shape");
+  hipLaunchKernelGGL(beam_update_kernel, dim3(d->batch), dim3(256), 0, (hipStream_t)stream, *d);
+  NS_CHECK_LAUNCH("ns_beam_update");
+  return NS_OK;
+}
+
+extern "C" int ns_anc_update(const int* anc_in, int* anc_out, const int* parent, int rows, int ld, int cur, const int* cur_dev,
+                             void* stream) {
+  NS_CHECK_ARG(anc_in && anc_out && rows > 0 && ld > 0, "ns_anc_update: bad arguments");
+  hipLaunchKernelGGL(anc_update_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, anc_in, anc_out, parent, rows, ld, cur,
+                     cur_dev);
+  NS_CHECK_LAUNCH("ns_anc_update");
+  return NS_OK;
+}
+
+extern "C" int ns_greedy_update(const float* scores, int rows, int V, int64_t* seqs, int ld, int cur, const int* cur_dev, int eos,
+                                int pad, unsigned char* done, int* any_open, int64_t* next_tok, void* stream) {
+  NS_CHECK_ARG(scores && seqs && done && any_open && next_tok && rows > 0 && V > 0, "ns_greedy_update: bad arguments");
+  hipLaunchKernelGGL(greedy_update_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, V, seqs, ld, cur, cur_dev, eos,
+                     pad, done, any_open, next_tok);
+  NS_CHECK_LAUNCH("ns_greedy_update");
+  return NS_OK;
+}

@@ -1,0 +1,159 @@
+"""Greedy / beam-search generation on top of the engine's weights (evaluation.py:369-386 call shape).
+
+Design notes (MI355X-first):
+  * the encoder runs once; each decoder layer's cross-attention K/V is projected once per SEQUENCE and is
+    never duplicated per beam nor re-gathered: ns_attn_decode reads it once for all beams of the sequence;
+  * the self-attention cache is laid out [position][slot]; beams are reordered by rewriting a small int32
+    ancestry table (which slot holds my token-p K/V) instead of index_select-ing every cache tensor;
+  * logits processors, top-2k selection and the HF beam bookkeeping run on the device; the host only polls a
+    two-word flag every `check_every` steps.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import rowmap
+
+F16, F32 = torch.float16, torch.float32
+
+
+class Generator:
+    def __init__(self, engine):
+        self.eng = engine
+
+    @torch.no_grad()
+    def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
+                 repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0, suppress_tokens=(),
+                 begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
+                 pad_id: int | None = None, check_every: int = 4) -> torch.Tensor:
+        eng = self.eng
+        dims, dev = eng.dims, eng.dev
+        d, H, S, V, Vp = dims.d, dims.heads, dims.src_pos, dims.vocab, dims.vocab_pad
+        eos = dims.eos_id if eos_id is None else eos_id
+        pad = dims.pad_id if pad_id is None else pad_id
+        B, P = prompt.shape
+        nb = num_beams
+        Bp = B * nb
+        max_len = min(P + max_new_tokens, dims.tgt_pos)
+        # ---- encoder + per-sequence cross K/V
+        eng.training_mode = False
+        eng._cur_seed = 0
+        b = eng._alloc(B, 0, False)
+        eng._b = b
+        enc16 = eng.encode(x32.contiguous(), b, False)
+        M = B * S
+        kvx = []
+        for Lw in eng.dec:
+            t = torch.empty(M, 2 * d, device=dev, dtype=F16)
+            eng._lin(enc16, M, Lw["ckv"], C16=t)
+            kvx.append(t)
+        # ---- decode state
+        nl = dims.dec_layers
+        kvc = [torch.zeros(max_len * Bp, 2 * d, device=dev, dtype=F16) for _ in range(nl)]
+        anc = [torch.zeros(Bp, max_len, device=dev, dtype=torch.int32) for _ in range(2)]
+        h = [torch.empty(Bp, d, device=dev, dtype=F32) for _ in range(2)]
+        x16 = torch.empty(Bp, d, device=dev, dtype=F16)
+        qkv = torch.empty(Bp, 3 * d, device=dev, dtype=F16)
+        qc = torch.empty(Bp, d, device=dev, dtype=F16)
+        ao = torch.empty(Bp, d, device=dev, dtype=F16)
+        pre = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
+        gf = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
+        st = (torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
+        logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
+        scores = torch.empty(Bp, V, device=dev, dtype=F32)
+
+        def step(tok: torch.Tensor, t: int, parent):
+            """Feed token `tok` (Bp,) at position t; leaves last-position logits in `logits`."""
+            ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t)
+            anc.reverse()
+            a = anc[0]
+            ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t)
+            for li, Lw in enumerate(eng.dec):
+                ops.layernorm_fwd(h[0], *Lw["ln1"], x16, *st, Bp, d)
+                eng._lin(x16, Bp, Lw["qkv"], C16=qkv)
+                kvc[li].view(max_len, Bp, 2 * d)[t].copy_(qkv[:, d:])
+                ops.attn_decode(Q=qkv, K=kvc[li], V=(kvc[li], d), O=ao, groups=Bp, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
+                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a, anc_ld=max_len, kv_pos_stride=Bp)
+                eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
+                ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
+                eng._lin(x16, Bp, Lw["cq"], C16=qc)
+                ops.attn_decode(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, groups=B, nq=nb, H=H, Lk=S, Lk_max=S, ldq=d,
+                                ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
+                eng._lin(ao, Bp, Lw["cout"], R32=h[1], H32=h[0])
+                ops.layernorm_fwd(h[0], *Lw["ln3"], x16, *st, Bp, d)
+                eng._lin(x16, Bp, Lw["fc1"], C16=pre, G16=gf, gelu=True)
+                eng._lin(gf, Bp, Lw["fc2"], R32=h[0], H32=h[1])
+                h.reverse()
+            ops.layernorm_fwd(h[0], *eng.dec_ln, x16, *st, Bp, d)
+            ops.gemm(A=x16, am=rowmap(d), K=d, B=eng.E16, ldb=d, M=Bp, N=Vp, C16=logits, c16m=rowmap(Vp))
+
+        sup = torch.tensor(list(suppress_tokens), device=dev, dtype=torch.int32) if len(suppress_tokens) else None
+        bsup = torch.tensor(list(begin_suppress_tokens), device=dev, dtype=torch.int32) if len(begin_suppress_tokens) else None
+        proc = dict(logits16=logits, scores32=scores, rows=Bp, V=V, ldv=Vp, ids_ld=max_len, begin_index=P,
+                    repetition_penalty=float(repetition_penalty), no_repeat_ngram=int(no_repeat_ngram_size),
+                    suppress=sup, n_suppress=len(suppress_tokens), begin_suppress=bsup,
+                    n_begin_suppress=len(begin_suppress_tokens))
+
+        seqs = [torch.full((Bp, max_len), pad, device=dev, dtype=torch.int64) for _ in range(2)]
+        seqs[0][:, :P] = prompt.repeat_interleave(nb, 0)
+        for t in range(P):
+            step(seqs[0][:, t].contiguous(), t, None)
+        flags = torch.zeros(2, device=dev, dtype=torch.int32)
+        next_tok = torch.empty(Bp, device=dev, dtype=torch.int64)
+        cur = P
+
+        if nb == 1:
+            done = torch.zeros(Bp, device=dev, dtype=torch.uint8)
+            while cur < max_len:
+                ops.logits_process(ids=seqs[0], cur_len=cur, log_softmax=False, **proc)
+                flags.zero_()
+                ops.greedy_update(scores, Bp, V, seqs[0], max_len, cur, eos, pad, done, flags, next_tok)
+                cur += 1
+                if cur >= max_len:
+                    break
+                if (cur - P) % check_every == 0 and flags[0].item() == 0:
+                    break
+                step(next_tok, cur - 1, None)
+            out = seqs[0]
+        else:
+            run_scores = [torch.zeros(B, nb, device=dev, dtype=F32) for _ in range(2)]
+            run_scores[0][:, 1:] = -1e9
+            fin_seqs = [seqs[0].clone(), seqs[0].clone()]
+            fin_scores = [torch.full((B, nb), -1e9, device=dev, dtype=F32) for _ in range(2)]
+            fin_done = [torch.zeros(B, nb, device=dev, dtype=torch.uint8) for _ in range(2)]
+            open_row = torch.ones(B, device=dev, dtype=torch.uint8)
+            top_v = torch.empty(B, 2 * nb, device=dev, dtype=F32)
+            top_i = torch.empty(B, 2 * nb, device=dev, dtype=torch.int32)
+            parent = torch.empty(Bp, device=dev, dtype=torch.int32)
+            while True:
+                ops.logits_process(ids=seqs[0], cur_len=cur, log_softmax=True, beam_scores=run_scores[0], **proc)
+                ops.topk_groups(scores, B, nb * V, 2 * nb, top_v, top_i)
+                flags.zero_()
+                ops.beam_update(top_vals=top_v, top_idx=top_i, run_seqs_in=seqs[0], run_seqs_out=seqs[1],
+                                run_scores_out=run_scores[1], fin_seqs_in=fin_seqs[0], fin_seqs_out=fin_seqs[1],
+                                fin_scores_in=fin_scores[0], fin_scores_out=fin_scores[1], fin_done_in=fin_done[0],
+                                fin_done_out=fin_done[1], open=open_row, parent_out=parent, next_tok_out=next_tok,
+                                any_open=flags, any_continuation=(flags, 1), cur_len_dev=None, batch=B, num_beams=nb,
+                                V=V, max_len=max_len, cur_len=cur, prompt_len=P, eos_id=eos,
+                                length_penalty=float(length_penalty))
+                for pair in (seqs, run_scores, fin_seqs, fin_scores, fin_done):
+                    pair.reverse()
+                cur += 1
+                if cur >= max_len:
+                    break
+                if (cur - P) % check_every == 0:
+                    f = flags.tolist()
+                    if f[0] == 0 or f[1] == 0:
+                        break
+                step(next_tok, cur - 1, parent)
+            out = fin_seqs[0].view(B, nb, max_len)[:, 0]
+            self.last_scores = fin_scores[0][:, 0].clone()
+        # crop like HF: up to the longest hypothesis (a hypothesis ends at its first EOS after the prompt)
+        o = out.cpu()
+        gen = o[:, P:]
+        is_eos = gen == eos
+        first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((o.shape[0],), gen.shape[1]))
+        width = P + int(first.max().item()) if gen.shape[1] > 0 else P
+        width = min(width, cur)
+        return out[:, :width].contiguous()

@@ -72,6 +72,44 @@ class AdamWCfg(C.Structure):
     ]
 
 
+class AttnDecodeDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+        ("anc", C.c_void_p), ("kv_len_dev", C.c_void_p),
+        ("groups", C.c_int32), ("nq", C.c_int32), ("H", C.c_int32), ("Lk", C.c_int32), ("Lk_max", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("anc_ld", C.c_int32),
+        ("kv_group_stride", C.c_int64), ("kv_pos_stride", C.c_int64),
+    ]
+
+
+class LogitsProcDesc(C.Structure):
+    _fields_ = [
+        ("logits16", C.c_void_p), ("scores32", C.c_void_p), ("ids", C.c_void_p), ("beam_scores", C.c_void_p),
+        ("suppress", C.c_void_p), ("begin_suppress", C.c_void_p), ("cur_len_dev", C.c_void_p),
+        ("rows", C.c_int32), ("V", C.c_int32), ("ldv", C.c_int32), ("ids_ld", C.c_int32), ("cur_len", C.c_int32),
+        ("begin_index", C.c_int32),
+        ("n_suppress", C.c_int32), ("n_begin_suppress", C.c_int32), ("no_repeat_ngram", C.c_int32),
+        ("log_softmax", C.c_int32),
+        ("repetition_penalty", C.c_float),
+    ]
+
+
+class BeamDesc(C.Structure):
+    _fields_ = [
+        ("top_vals", C.c_void_p), ("top_idx", C.c_void_p),
+        ("run_seqs_in", C.c_void_p), ("run_seqs_out", C.c_void_p), ("run_scores_out", C.c_void_p),
+        ("fin_seqs_in", C.c_void_p), ("fin_seqs_out", C.c_void_p),
+        ("fin_scores_in", C.c_void_p), ("fin_scores_out", C.c_void_p),
+        ("fin_done_in", C.c_void_p), ("fin_done_out", C.c_void_p),
+        ("open", C.c_void_p), ("parent_out", C.c_void_p), ("next_tok_out", C.c_void_p),
+        ("any_open", C.c_void_p), ("any_continuation", C.c_void_p), ("cur_len_dev", C.c_void_p),
+        ("batch", C.c_int32), ("num_beams", C.c_int32), ("V", C.c_int32), ("max_len", C.c_int32),
+        ("cur_len", C.c_int32), ("prompt_len", C.c_int32), ("eos_id", C.c_int32),
+        ("length_penalty", C.c_float),
+    ]
+
+
 NS_GEMM_GELU, NS_GEMM_DGELU, NS_GEMM_TN, NS_GEMM_ATOMIC32, NS_GEMM_DROP_A = 1, 2, 4, 8, 16
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -94,6 +132,12 @@ SIGNATURES = {
     "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ns_argmax_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "ns_attn_decode": (C.c_int, [C.POINTER(AttnDecodeDesc), _vp]),
+    "ns_logits_process": (C.c_int, [C.POINTER(LogitsProcDesc), _vp]),
+    "ns_topk_groups": (C.c_int, [_vp, _i, C.c_longlong, _i, _vp, _vp, _vp]),
+    "ns_beam_update": (C.c_int, [C.POINTER(BeamDesc), _vp]),
+    "ns_anc_update": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ns_greedy_update": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ns_grad_norm_workspace_bytes": (C.c_size_t, []),
     "ns_grad_norm": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "ns_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.POINTER(AdamWCfg), _vp, _vp, _vp, _vp, _vp, _vp]),

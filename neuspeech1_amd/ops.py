@@ -153,3 +153,47 @@ def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
 
 def cast_jobs(table: torch.Tensor, njobs: int):
     L.check(L.load().ns_cast_jobs(ptr(table), njobs, _stream()), "ns_cast_jobs")
+
+
+# ----------------------------------------------------------------------------- decode loop
+def attn_decode(*, Q, K, V, O, groups, nq, H, Lk, Lk_max, ldq, ldk, ldv, ldo, anc=None, anc_ld=0, kv_group_stride=0,
+                kv_pos_stride=0, kv_len_dev=None):
+    d = L.AttnDecodeDesc()
+    d.Q, d.K, d.V, d.O = ptr(Q), ptr(K), ptr(V), ptr(O)
+    d.anc, d.kv_len_dev = ptr(anc), ptr(kv_len_dev)
+    d.groups, d.nq, d.H, d.Lk, d.Lk_max, d.head_dim = groups, nq, H, Lk, Lk_max, 64
+    d.ldq, d.ldk, d.ldv, d.ldo, d.anc_ld = ldq, ldk, ldv, ldo, anc_ld
+    d.kv_group_stride, d.kv_pos_stride = kv_group_stride, kv_pos_stride
+    L.check(L.load().ns_attn_decode(C.byref(d), _stream()), "ns_attn_decode")
+
+
+def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, beam_scores=None,
+                   repetition_penalty=1.0, no_repeat_ngram=0, suppress=None, n_suppress=0, begin_suppress=None,
+                   n_begin_suppress=0, cur_len_dev=None):
+    d = L.LogitsProcDesc()
+    d.logits16, d.scores32, d.ids, d.beam_scores = ptr(logits16), ptr(scores32), ptr(ids), ptr(beam_scores)
+    d.suppress, d.begin_suppress, d.cur_len_dev = ptr(suppress), ptr(begin_suppress), ptr(cur_len_dev)
+    d.rows, d.V, d.ldv, d.ids_ld, d.cur_len, d.begin_index = rows, V, ldv, ids_ld, cur_len, begin_index
+    d.n_suppress, d.n_begin_suppress, d.no_repeat_ngram, d.log_softmax = n_suppress, n_begin_suppress, no_repeat_ngram, int(log_softmax)
+    d.repetition_penalty = repetition_penalty
+    L.check(L.load().ns_logits_process(C.byref(d), _stream()), "ns_logits_process")
+
+
+def topk_groups(x32, groups, n, k, vals, idx):
+    L.check(L.load().ns_topk_groups(ptr(x32), groups, n, k, ptr(vals), ptr(idx), _stream()), "ns_topk_groups")
+
+
+def beam_update(**kw):
+    d = L.BeamDesc()
+    for k, v in kw.items():
+        setattr(d, k, ptr(v) if isinstance(v, (torch.Tensor, tuple)) or v is None else v)
+    L.check(L.load().ns_beam_update(C.byref(d), _stream()), "ns_beam_update")
+
+
+def anc_update(anc_in, anc_out, parent, rows, ld, cur):
+    L.check(L.load().ns_anc_update(ptr(anc_in), ptr(anc_out), ptr(parent), rows, ld, cur, 0, _stream()), "ns_anc_update")
+
+
+def greedy_update(scores, rows, V, seqs, ld, cur, eos, pad, done, any_open, next_tok):
+    L.check(L.load().ns_greedy_update(ptr(scores), rows, V, ptr(seqs), ld, cur, 0, eos, pad, ptr(done), ptr(any_open),
+                                      ptr(next_tok), _stream()), "ns_greedy_update")

@@ -234,9 +234,10 @@ def suppress_(scores, suppress_tokens, begin_suppress, cur_len, begin_index):
 
 
 def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repeat_ngram_size=0,
-           suppress_tokens=(), begin_suppress_tokens=()):
+           suppress_tokens=(), begin_suppress_tokens=(), eos_id=None):
     """HF:generation/utils.py:2783-2975 (greedy search): processors act on raw last-position logits
     (fp32), argmax, finished rows emit pad.  Returns prompt + new tokens (GenerationMixin semantics)."""
+    eos_id = dims.eos_id if eos_id is None else eos_id
     enc = encoder(sd, x, dims)
     ids = prompt.clone()
     Bn = ids.shape[0]
@@ -252,34 +253,44 @@ def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repea
         nxt = s.argmax(-1)
         nxt = torch.where(done, torch.full_like(nxt, dims.pad_id), nxt)
         ids = torch.cat([ids, nxt[:, None]], 1)
-        done = done | (nxt == dims.eos_id)
+        done = done | (nxt == eos_id)
         if bool(done.all()):
             break
     return ids
 
 
 def beam_search(sd, x, dims, prompt, num_beams, max_new_tokens, repetition_penalty=1.0, no_repeat_ngram_size=0,
-                suppress_tokens=(), begin_suppress_tokens=(), length_penalty=1.0, max_length=None):
-    """HF:generation/utils.py:3077-3480 (vectorised beam search, early_stopping=False, do_sample=False):
-    log_softmax -> processors (on log-probs) -> + running beam scores -> top-(2*beams) over beams*V ->
-    finished candidates scored / (cur_len+1-prompt_len)^lp compete for the best `beams` hypotheses ->
-    the best `beams` unfinished continue.  Stops when no running beam can beat the worst kept hypothesis
-    or at max length.  Returns the best hypothesis per batch row, padded with pad_id."""
+                suppress_tokens=(), begin_suppress_tokens=(), length_penalty=1.0, eos_id=None):
+    """HF:generation/utils.py:3208-3545 (_beam_search, do_sample=False, early_stopping=False) with its helpers
+    :3077-3129 (_get_top_k_continuations), :3131-3152 (_get_running_beams_for_next_iteration), :3154-3204
+    (_update_finished_beams), :3008-3053 (_check_early_stop_heuristic), :3055-3075 (loop condition).
+
+    Per step at length cur: log_softmax -> processors (on log-probs) -> + running beam scores -> top-(2*beams)
+    over beams*V.  A candidate "hits" when its token is EOS or when cur+1 reaches max_length.  The next running
+    beams are the best `beams` non-hit candidates.  Hit candidates of rank < beams enter the finished set with score
+    / (cur+1-prompt)^lp -- unless the row's early-stop heuristic has already been satisfied (sticky) -- and the best
+    `beams` finished hypotheses are kept.  Heuristic (after cur += 1): the row stays open while some finished slot is
+    empty or running_best / (cur-prompt)^lp > worst finished score.  The loop ends when no row is open or every
+    candidate hit (max length).  Returns finished hypothesis 0 of each row, padded with pad_id."""
+    eos_id = dims.eos_id if eos_id is None else eos_id
     enc = encoder(sd, x, dims)
     Bn, P = prompt.shape
     V = dims.vocab
     nb = num_beams
-    max_len = P + max_new_tokens if max_length is None else max_length
+    max_len = P + max_new_tokens
     enc_b = enc.repeat_interleave(nb, 0)
-    running = prompt[:, None, :].repeat(1, nb, 1)                       # (B, nb, cur)
+    running = torch.full((Bn, nb, max_len), dims.pad_id, dtype=torch.long)
+    running[:, :, :P] = prompt[:, None, :]
     run_scores = torch.zeros(Bn, nb)
     run_scores[:, 1:] = -1e9
-    fin_seqs = torch.full((Bn, nb, max_len), dims.pad_id, dtype=torch.long)
+    fin_seqs = running.clone()
     fin_scores = torch.full((Bn, nb), -1e9)
     fin_done = torch.zeros(Bn, nb, dtype=torch.bool)
+    open_row = torch.ones(Bn, 1, dtype=torch.bool)          # is_early_stop_heuristic_unsatisfied
+    rank_ok = (torch.arange(2 * nb) < nb)[None, :]
     cur = P
-    while cur < max_len:
-        flat = running.reshape(Bn * nb, cur)
+    while True:
+        flat = running[:, :, :cur].reshape(Bn * nb, cur)
         logits = _decoder_logits_last(sd, flat, enc_b, dims).float()
         lp = F.log_softmax(logits, -1)
         if repetition_penalty != 1.0:
@@ -291,48 +302,33 @@ def beam_search(sd, x, dims, prompt, num_beams, max_new_tokens, repetition_penal
         top, idx = torch.topk(tot, 2 * nb, dim=1)
         beam_idx = idx // V
         tok = idx % V
-        cand = torch.cat([torch.gather(running, 1, beam_idx[:, :, None].expand(-1, -1, cur)), tok[:, :, None]], 2)
-        cur += 1
-        is_eos = tok == dims.eos_id
-        # --- update finished set
-        fin_cand = top / float(cur - P) ** length_penalty if length_penalty != 0 else top.clone()
-        # a finished candidate only counts if it is among the first nb candidates... HF keeps all 2nb but masks
-        # those beyond rank nb:  did_topk_just_finished = eos & (rank < nb)
-        rank_ok = torch.arange(2 * nb)[None, :] < nb
-        fin_cand = torch.where(is_eos & rank_ok, fin_cand, torch.full_like(fin_cand, -1e9))
-        if cur == max_len:                      # forced finish of every running continuation at max length
-            pass
-        all_scores = torch.cat([fin_scores, fin_cand], 1)
-        pad = torch.full((Bn, 2 * nb, max_len - cur), dims.pad_id, dtype=torch.long)
-        all_seqs = torch.cat([fin_seqs, torch.cat([cand, pad], 2)], 1)
-        all_done = torch.cat([fin_done, is_eos & rank_ok], 1)
+        cand = torch.gather(running, 1, beam_idx[:, :, None].expand(-1, -1, max_len)).clone()
+        cand[:, :, cur] = tok
+        hits = (tok == eos_id) | (cur + 1 >= max_len)
+        # next running beams
+        run_cand = top + hits.float() * -1.0e9
+        rs, ri = torch.topk(run_cand, nb, dim=1)
+        running = torch.gather(cand, 1, ri[:, :, None].expand(-1, -1, max_len))
+        run_scores = rs
+        # finished set
+        just = hits & rank_ok
+        fc = top / float(cur + 1 - P) ** length_penalty
+        fc = fc + (~open_row).float() * -1.0e9
+        fc = fc + (~just).float() * -1.0e9
+        all_scores = torch.cat([fin_scores, fc], 1)
+        all_seqs = torch.cat([fin_seqs, cand], 1)
+        all_done = torch.cat([fin_done, just], 1)
         ts, ti = torch.topk(all_scores, nb, dim=1)
         fin_scores = ts
         fin_seqs = torch.gather(all_seqs, 1, ti[:, :, None].expand(-1, -1, max_len))
         fin_done = torch.gather(all_done, 1, ti)
-        # --- next running beams: best nb non-eos candidates
-        run_cand = torch.where(is_eos, torch.full_like(top, -1e9), top)
-        rs, ri = torch.topk(run_cand, nb, dim=1)
-        running = torch.gather(cand, 1, ri[:, :, None].expand(-1, -1, cur))
-        run_scores = rs
-        # --- stopping: early_stopping=False -> best possible running score (length-normalised at max length
-        # when lp > 0, else at cur length) cannot beat the worst finished one, and nb hypotheses are finished
-        if length_penalty > 0.0:
-            best_run = run_scores[:, 0] / float(max_len - P) ** length_penalty
-        else:
-            best_run = run_scores[:, 0] / float(cur - P) ** length_penalty if length_penalty != 0 else run_scores[:, 0]
-        worst_fin = torch.where(fin_done, fin_scores, torch.full_like(fin_scores, -1e9)).min(1).values
-        still_open = ~(fin_done.all(1)) | (best_run > worst_fin)
-        if not bool(still_open.any()):
+        cur += 1
+        best_run = run_scores[:, :1] / float(cur - P) ** length_penalty
+        worst = torch.where(fin_done, fin_scores.min(1, keepdim=True).values, torch.full_like(fin_scores, -1.0e9))
+        open_row = open_row & (best_run > worst).any(-1, keepdim=True)
+        if not bool(open_row.any()) or bool(hits.all()):
             break
-    # batches with fewer than nb finished hypotheses fall back to the running beams
-    out = torch.full((Bn, max_len), dims.pad_id, dtype=torch.long)
-    for b in range(Bn):
-        if bool(fin_done[b].any()):
-            out[b] = fin_seqs[b, 0]
-        else:
-            out[b, :cur] = running[b, 0]
-    return out
+    return fin_seqs[:, 0]
 
 
 # --------------------------------------------------------------------------- data feed

@@ -1,0 +1,99 @@
+"""Decode parity on the GPU: greedy / beam-search token ids of the HIP path against the golden ids produced by the
+reference object (HF GenerationMixin on stock Whisper + the reference's projection_module; tools/make_goldens.py).
+Bar: token-id exact (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neuspeech1_amd.weights import TINY, make_state_dict, synth_batch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from neuspeech1_amd.engine import MegWhisperEngine
+    from neuspeech1_amd.generate import Generator
+    g = np.load(os.path.join(G, "decode_tiny.npz"))
+    dims = TINY
+    eng = MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev)
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    return g, dims, Generator(eng), torch.from_numpy(x).to(dev), torch.from_numpy(labels[:, :4].copy()).to(dev)
+
+
+def check(out, ref, pad):
+    out = out.cpu().numpy()
+    Lm = min(out.shape[1], ref.shape[1])
+    assert np.array_equal(out[:, :Lm], ref[:, :Lm]), f"\n{out.tolist()}\n{ref.tolist()}"
+    assert (out[:, Lm:] == pad).all() and (ref[:, Lm:] == pad).all()
+    assert out.shape[1] == ref.shape[1], (out.shape, ref.shape)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("greedy", {}),
+    ("greedy_rp", dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("greedy_eos34", dict(eos_id=34)),
+    ("greedy_eos630", dict(eos_id=630)),
+])
+def test_greedy_token_ids_exact(setup, name, kw):
+    g, dims, gen, x, prompt = setup
+    out = gen.generate(x, prompt, num_beams=1, max_new_tokens=int(g["new_tokens"]), check_every=1, **kw)
+    check(out, g[name], dims.pad_id)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("beam5", {}),
+    ("beam5_rp", dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("beam5_eos34", dict(eos_id=34)),
+    ("beam5_rp_eos34", dict(repetition_penalty=5.0, no_repeat_ngram_size=2, eos_id=34)),
+    ("beam5_eos630", dict(eos_id=630)),
+    ("beam5_rp_eos630", dict(repetition_penalty=5.0, no_repeat_ngram_size=2, eos_id=630)),
+])
+def test_beam_search_token_ids_exact(setup, name, kw):
+    g, dims, gen, x, prompt = setup
+    out = gen.generate(x, prompt, num_beams=5, max_new_tokens=int(g["new_tokens"]), check_every=1, **kw)
+    check(out, g[name], dims.pad_id)
+    np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[name + "_scores"], atol=2e-2)
+
+
+def test_delayed_stop_check_gives_same_ids(setup):
+    g, dims, gen, x, prompt = setup
+    a = gen.generate(x, prompt, num_beams=5, max_new_tokens=24, eos_id=630, check_every=1)
+    b = gen.generate(x, prompt, num_beams=5, max_new_tokens=24, eos_id=630, check_every=4)
+    assert torch.equal(a, b)
+
+
+def test_processors_and_topk_kernels(dev):
+    """ns_logits_process / ns_topk_groups against torch on hand-built cases (G5 of SURVEY.md §8c)."""
+    from neuspeech1_amd import ops
+    from oracle import whisper_meg_oracle as O
+    torch.manual_seed(0)
+    rows, V, ldv, L = 6, 1000, 1024, 12
+    logits = torch.zeros(rows, ldv, device=dev, dtype=torch.float16)
+    logits[:, :V] = (torch.randn(rows, V, device=dev) * 3).half()
+    ids = torch.randint(0, 50, (rows, L), device=dev)
+    cur = 9
+    ids[0, 3:5] = ids[0, 7:9]          # a repeated bigram prefix -> ban
+    bs = torch.randn(rows, device=dev)
+    scores = torch.empty(rows, V, device=dev)
+    sup = torch.tensor([5, 6], device=dev, dtype=torch.int32)
+    ops.logits_process(logits16=logits, scores32=scores, ids=ids, rows=rows, V=V, ldv=ldv, ids_ld=L, cur_len=cur,
+                       begin_index=cur, log_softmax=True, beam_scores=bs, repetition_penalty=5.0, no_repeat_ngram=2,
+                       suppress=sup, n_suppress=2, begin_suppress=sup, n_begin_suppress=1)
+    ref = torch.log_softmax(logits[:, :V].float().cpu(), -1)
+    O.repetition_penalty_(ref, ids[:, :cur].cpu(), 5.0)
+    O.no_repeat_ngram_(ref, ids[:, :cur].cpu(), 2)
+    O.suppress_(ref, [5, 6], [5], cur, cur)
+    ref = ref + bs.cpu()[:, None]
+    got = scores.cpu()
+    assert torch.equal(torch.isinf(got), torch.isinf(ref))
+    fin = ~torch.isinf(ref)
+    torch.testing.assert_close(got[fin], ref[fin], atol=2e-3, rtol=1e-4)
+    vals = torch.empty(2, 10, device=dev)
+    idx = torch.empty(2, 10, device=dev, dtype=torch.int32)
+    ops.topk_groups(scores, 2, 3 * V, 10, vals, idx)
+    rv, ri = torch.topk(scores.view(2, 3 * V), 10, dim=1)
+    assert torch.equal(vals, rv) and torch.equal(idx.long(), ri)

@@ -84,3 +84,31 @@ def test_reader_collate_and_matchers():
     got = O.match_modules_string(names, ["model.encoder"], ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"])
     assert len(got) == 36 and all(n.startswith("model.encoder.layers.") for n in got)
     assert O.shift_tokens_right(torch.tensor([[5, 6, -100]]), 9, 1).tolist() == [[1, 5, 6]]
+
+
+def test_oracle_decode_matches_reference_generate():
+    """greedy + beam-5 (with/without repetition penalty 5.0 + no-repeat-2, with EOS finishing) vs HF GenerationMixin."""
+    g = np.load(os.path.join(G, "decode_tiny.npz"))
+    dims = TINY
+    sd = O.to_torch(make_state_dict(dims, 42))
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    prompt = torch.from_numpy(labels[:, :4].copy())
+    xt = torch.from_numpy(x)
+    n = int(g["new_tokens"])
+
+    def same(name, a):
+        ref, a = g[name], a.numpy()
+        Lm = min(a.shape[1], ref.shape[1])
+        assert np.array_equal(a[:, :Lm], ref[:, :Lm]), name
+        assert (a[:, Lm:] == dims.pad_id).all() and (ref[:, Lm:] == dims.pad_id).all(), name
+
+    rp = dict(repetition_penalty=5.0, no_repeat_ngram_size=2)
+    with torch.no_grad():
+        same("greedy", O.greedy(sd, xt, dims, prompt, n))
+        same("greedy_rp", O.greedy(sd, xt, dims, prompt, n, **rp))
+        same("beam5", O.beam_search(sd, xt, dims, prompt, 5, n))
+        same("beam5_rp", O.beam_search(sd, xt, dims, prompt, 5, n, **rp))
+        for eos in (34, 630):
+            same(f"greedy_eos{eos}", O.greedy(sd, xt, dims, prompt, n, eos_id=eos))
+            same(f"beam5_eos{eos}", O.beam_search(sd, xt, dims, prompt, 5, n, eos_id=eos))
+            same(f"beam5_rp_eos{eos}", O.beam_search(sd, xt, dims, prompt, 5, n, eos_id=eos, **rp))

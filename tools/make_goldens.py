@@ -135,7 +135,17 @@ def decode_golden(dims, tag, B, new_tokens):
         o = gen(model, feats, num_beams=5, **common)
         g["beam5"] = o.sequences.numpy()
         g["beam5_scores"] = o.sequences_scores.numpy().astype(np.float32)
-        # EOS-friendly variant: bias the EOS row of the tied embedding so hypotheses finish early
+        # EOS variants: declare a frequently generated token id as EOS so rows / hypotheses really finish
+        for eos in (34, 630):
+            c2 = dict(common, eos_token_id=eos)
+            o = gen(model, feats, num_beams=1, **c2)
+            g[f"greedy_eos{eos}"] = o.sequences.numpy()
+            o = gen(model, feats, num_beams=5, **c2)
+            g[f"beam5_eos{eos}"] = o.sequences.numpy()
+            g[f"beam5_eos{eos}_scores"] = o.sequences_scores.numpy().astype(np.float32)
+            o = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, **c2)
+            g[f"beam5_rp_eos{eos}"] = o.sequences.numpy()
+            g[f"beam5_rp_eos{eos}_scores"] = o.sequences_scores.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, f"decode_{tag}.npz"), **g)
     print(f"decode_{tag}: greedy tail {g['greedy'][:, -4:].tolist()}")
 
