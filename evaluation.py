@@ -1,0 +1,135 @@
+"""Decode a MEG test list with beam search on MI355X (drop-in for the reference evaluation.py: same flags, same
+result files `<lora_model>/formal_test_results*.{txt,jsonl,json}`).
+
+The decode call is the reference's (evaluation.py:369-386): do_sample=False, num_beams=5, repetition_penalty=5.0,
+no_repeat_ngram_size=2, decoder_input_ids = labels[:, :4] for non-English data; --teacher_forcing takes the
+argmax of one teacher-forced forward (evaluation.py:392-403).  Text metrics (BLEU/ROUGE/WER/...: `evaluate`,
+`torchmetrics`, `nltk`, ... are not in the image) are out of the hot path: the json result holds throughput and
+token-level accuracy instead.
+"""
+import argparse
+import functools
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from neuspeech1_amd.peft_compat import PeftModel
+from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding
+from utils.load_model import WhisperForConditionalGeneration
+from utils.model_utils import projection_module
+from utils.reader import CustomDataset, write_jsonlines
+from utils.utils import add_arguments, print_arguments
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    add_arg = functools.partial(add_arguments, argparser=parser)
+    add_arg("test_data", type=str, default="dataset/test_data.jsonl", help="test list (jsonl)")
+    add_arg("model_path", type=str, default="models/whisper-tiny-finetune", help="merged model dir or synthetic:<size>")
+    add_arg("lora_model", type=str, default=None, help="trained adapter directory (results are written there)")
+    add_arg("modal", type=str, default="speech", help="input modality")
+    add_arg("sampling_rate", type=int, default=1000, help="signal sample rate")
+    add_arg("eeg_ch", type=int, default=66, help="input channels")
+    add_arg("batch_size", type=int, default=16, help="decode batch size")
+    add_arg("num_workers", type=int, default=8, help="data loader workers")
+    add_arg("language", type=str, default="Chinese", help="language")
+    add_arg("remove_pun", type=bool, default=True, help="strip punctuation")
+    add_arg("to_simple", type=bool, default=True, help="to simplified Chinese")
+    add_arg("timestamps", type=bool, default=True, help="timestamp labels")
+    add_arg("min_audio_len", type=float, default=0.5, help="minimum length (s)")
+    add_arg("max_audio_len", type=float, default=30, help="maximum length (s)")
+    add_arg("local_files_only", type=bool, default=True, help="never download")
+    add_arg("noise", type=bool, default=False, help="feed noise instead of the signal")
+    add_arg("filter_dataset", type=bool, default=False, help="filter the data list")
+    add_arg("random_choice", type=bool, default=False, help="random label baseline")
+    add_arg("task", type=str, default="transcribe", choices=["transcribe", "translate"], help="task")
+    add_arg("random_initialize_whisper", type=bool, default=False, help="random init")
+    add_arg("teacher_forcing", type=bool, default=False, help="teacher-forced argmax instead of generate")
+    add_arg("extra_name", type=str, default=None, help="suffix for the result basename")
+    add_arg("post_processing", type=bool, default=False, help="ascii/lowercase post-processing")
+    add_arg("config_name", type=str, default="base", help="front-end module")
+    add_arg("add_sequence_bias", type=bool, default=False, help="sequence bias")
+    # additions of this build
+    add_arg("num_beams", type=int, default=5, help="beam width (reference: 5)")
+    add_arg("max_new_tokens", type=int, default=None, help="cap on generated tokens")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print_arguments(args)
+    if args.random_choice or args.add_sequence_bias:
+        raise NotImplementedError("--random_choice / --add_sequence_bias are outside the hot path")
+    assert args.model_path.startswith("synthetic:") or os.path.exists(args.model_path), f"model {args.model_path} not found"
+    from finetune import get_processor
+    processor = get_processor(args.model_path, args.language, args.task, args.timestamps, args.local_files_only)
+    model = WhisperForConditionalGeneration.from_pretrained(args.model_path, device_map="auto",
+                                                            local_files_only=args.local_files_only)
+    torch.manual_seed(42)
+    conv1 = projection_module(config_name=args.config_name, meg_ch=args.eeg_ch,
+                              d_model=model.model.encoder.conv2.in_channels).to(model.device)
+    model.model.encoder.set_input_embeddings(conv1)
+    out_dir = args.lora_model or "."
+    if args.lora_model is not None:
+        model = PeftModel.from_pretrained(model, args.lora_model, local_files_only=args.local_files_only)
+        model = model.merge_and_unload()
+    model.eval()
+    test_dataset = CustomDataset(data_list_path=args.test_data, processor=processor, timestamps=args.timestamps,
+                                 modal=args.modal, mode="test", modal_ch=args.eeg_ch, filter_dataset=args.filter_dataset,
+                                 sample_rate=args.sampling_rate, language=args.language,
+                                 min_duration=args.min_audio_len, max_duration=args.max_audio_len)
+    print(f"test samples: {len(test_dataset)}")
+    collator = DataCollatorSpeechSeq2SeqWithPadding(processor=processor)
+    loader = torch.utils.data.DataLoader(test_dataset, batch_size=args.batch_size, num_workers=args.num_workers,
+                                         collate_fn=collator)
+    base = (f'formal_test_results{"_" + args.extra_name if args.extra_name is not None else ""}'
+            f'{"no_post_processing" if not args.post_processing else "post_processing"}'
+            f'{"_noise" if args.noise else ""}{"_tf" if args.teacher_forcing else ""}')
+    preds, refs = [], []
+    n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
+    with open(os.path.join(out_dir, base + ".txt"), "w") as f, torch.no_grad():
+        for batch in loader:
+            x = batch["input_features"].to(model.device)
+            if args.noise:
+                x = torch.randn_like(x)
+            labels = batch["labels"]
+            if not args.teacher_forcing:
+                kw = {}
+                if args.language.lower() != "english":
+                    kw["decoder_input_ids"] = labels[:, :4].to(model.device)
+                if args.max_new_tokens is not None:
+                    kw["max_new_tokens"] = args.max_new_tokens
+                gen = model.generate(x, do_sample=False, num_beams=args.num_beams, repetition_penalty=5.0,
+                                     no_repeat_ngram_size=2, **kw).cpu().numpy()
+                n_new += int(gen.shape[0] * (gen.shape[1] - (4 if kw.get("decoder_input_ids") is not None else 1)))
+            else:
+                ign = labels == -100
+                fed = labels.masked_fill(ign, model.config.eos_token_id)
+                logits = model(input_features=x, decoder_input_ids=fed.to(model.device)).logits
+                gen = logits.argmax(-1).cpu()
+                n_match += int(((gen[:, :-1] == labels[:, 1:]) & ~ign[:, 1:]).sum())
+                n_lab += int((~ign[:, 1:]).sum())
+                gen = gen.masked_fill(ign, -100).numpy()
+            lab = np.where(labels.numpy() != -100, labels.numpy(), processor.tokenizer.pad_token_id)
+            dp = processor.batch_decode(gen, skip_special_tokens=True)
+            dl = processor.batch_decode(lab, skip_special_tokens=True)
+            preds.extend(dp)
+            refs.extend(dl)
+            for p, l in zip(dp, dl):
+                f.write("start********************************\n")
+                f.write(f"Predicted: {p}\nTrue: {l}\n")
+                f.write("end==================================\n\n")
+    dt = time.time() - t0
+    write_jsonlines(os.path.join(out_dir, base + ".jsonl"), [{"pred": p, "label": l} for p, l in zip(preds, refs)])
+    results = {"samples": len(preds), "seconds": round(dt, 3), "generated_tokens_per_s": round(n_new / dt, 2) if n_new else None,
+               "teacher_forced_token_accuracy": round(n_match / n_lab, 5) if n_lab else None}
+    print(f"results: {results}")
+    with open(os.path.join(out_dir, base + ".json"), "w") as f:
+        json.dump(results, f)
+
+
+if __name__ == "__main__":
+    main()

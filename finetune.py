@@ -1,0 +1,260 @@
+"""Fine-tune Whisper on MEG with LoRA + conv-stem training on MI355X (drop-in for the reference finetune.py:
+same flags, same defaults, same outputs), driven by the HIP engine instead of HF Trainer + peft:
+
+    python finetune.py --base_model=synthetic:base --modal=eeg --eeg_ch=208 --use_adalora=False --fp16=True ...
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 finetune.py ...   (data parallel)
+
+Per step (reference finetune.py:231-281 -> HF Trainer inner loop): forward, backward, RCCL all-reduce (AVG) of the
+flat trainable-gradient buffer overlapped with backward, GradScaler unscale + inf check, clip to 1.0, AdamW, linear
+warmup/decay; eval = loss only; a checkpoint is written only when the eval loss is the best so far
+(utils/callback.py:11-32) plus `checkpoint-final` at the end.
+"""
+import argparse
+import functools
+import json
+import math
+import os
+import time
+
+import torch
+
+from neuspeech1_amd.dp import GradReducer
+from neuspeech1_amd.engine import TrainCfg
+from neuspeech1_amd.peft_compat import AdaLoraConfig, LoraConfig, PeftModel, get_peft_model, prepare_model_for_kbit_training
+from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, get_part_of_dataset
+from utils.load_model import WhisperForConditionalGeneration, match_modules, match_modules_string
+from utils.model_utils import projection_module
+from utils.reader import CustomDataset
+from utils.utils import add_arguments, make_inputs_require_grad, print_arguments
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    add_arg = functools.partial(add_arguments, argparser=parser)
+    add_arg("train_data", type=str, default="dataset/train_data.jsonl", help="training list (jsonl)")
+    add_arg("test_data", type=str, default="dataset/val_data.jsonl", help="validation list (jsonl)")
+    add_arg("base_model", type=str, default="openai/whisper-base", help="Whisper base model dir or synthetic:<size>")
+    add_arg("lora_model", type=str, default=None, help="trained adapter to merge before training")
+    add_arg("output_dir", type=str, default="output1/", help="checkpoint directory")
+    add_arg("warmup_steps", type=int, default=10000, help="warm-up steps")
+    add_arg("logging_steps", type=int, default=100, help="log every N steps")
+    add_arg("eval_steps", type=int, default=1000, help="evaluate every N steps")
+    add_arg("save_steps", type=int, default=1000, help="checkpoint every N steps (only when eval loss is best)")
+    add_arg("num_workers", type=int, default=6, help="data loader workers")
+    add_arg("learning_rate", type=float, default=1e-3, help="learning rate")
+    add_arg("modal", type=str, default="speech", help="input modality")
+    add_arg("sampling_rate", type=int, default=200, help="expected signal sample rate")
+    add_arg("orig_sample_rate", type=int, default=200, help="signal sample rate on disk")
+    add_arg("eeg_ch", type=int, default=224, help="input channels")
+    add_arg("lora_eeg_ch", type=int, default=None, help="input channels of the adapter being merged")
+    add_arg("min_audio_len", type=float, default=0.5, help="minimum length (s)")
+    add_arg("max_audio_len", type=float, default=30, help="maximum length (s)")
+    add_arg("use_adalora", type=bool, default=True, help="AdaLoRA instead of LoRA")
+    add_arg("fp16", type=bool, default=False, help="fp16 training with dynamic loss scaling")
+    add_arg("use_8bit", type=bool, default=False, help="8-bit base model")
+    add_arg("filter_dataset", type=bool, default=False, help="filter the data list")
+    add_arg("timestamps", type=bool, default=True, help="use timestamp labels")
+    add_arg("local_files_only", type=bool, default=True, help="never download")
+    add_arg("num_train_epochs", type=int, default=30, help="epochs")
+    add_arg("language", type=str, default="English", help="language (None = multilingual)")
+    add_arg("task", type=str, default="transcribe", choices=["transcribe", "translate"], help="task")
+    add_arg("augment_config_path", type=str, default="configs/augmentation.json", help="augmentation config")
+    add_arg("resume_from_checkpoint", type=str, default=None, help="adapter checkpoint to resume from")
+    add_arg("per_device_train_batch_size", type=int, default=2, help="train batch per device")
+    add_arg("per_device_eval_batch_size", type=int, default=2, help="eval batch per device")
+    add_arg("gradient_accumulation_steps", type=int, default=1, help="gradient accumulation")
+    add_arg("fine_tune_layers", type=int, default=None, help="adapt only the first N encoder layers")
+    add_arg("device", type=str, default="auto", help="device")
+    add_arg("config_name", type=str, default="base", help="conv1 module")
+    add_arg("data_ratio", type=float, default=None, help="fraction of the training list to use")
+    add_arg("random_initialize_whisper", type=bool, default=False, help="random init")
+    add_arg("combine_sentences", type=bool, default=False, help="sentence combining")
+    add_arg("split_sentences", type=bool, default=False, help="sentence splitting")
+    add_arg("ft_full", type=bool, default=False, help="adapt the whole model")
+    # additions of this build (not in the reference)
+    add_arg("max_steps", type=int, default=-1, help="stop after N optimizer steps (smoke runs)")
+    return parser
+
+
+def get_processor(name, language, task, timestamps, local_files_only):
+    if name.startswith("synthetic:"):
+        from neuspeech1_amd.synthetic import SyntheticProcessor
+        from utils.load_model import _SYNTH
+        p = SyntheticProcessor(_SYNTH[name.split(":")[1]])
+        p.tokenizer.set_prefix_tokens(language=language)
+        return p
+    from transformers import WhisperProcessor
+    return WhisperProcessor.from_pretrained(name, language=language, task=task, no_timestamps=not timestamps,
+                                            local_files_only=local_files_only)
+
+
+def shard_indices(n, epoch, rank, world, seed=42, shuffle=True):
+    """torch DistributedSampler semantics: seeded shuffle, pad to a multiple of world, strided shard."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
+    total = math.ceil(n / world) * world
+    idx += idx[: total - n]
+    return idx[rank:total:world]
+
+
+def evaluate_loss(model, dataset, collator, batch_size, rank, world, num_workers):
+    eng = model.engine()
+    idx = shard_indices(len(dataset), 0, rank, world, shuffle=False)
+    tot, cnt = 0.0, 0
+    for i in range(0, len(idx), batch_size):
+        batch = collator([dataset[j] for j in idx[i:i + batch_size]])
+        loss, _ = eng.forward(batch["input_features"].to(model.device), batch["labels"].to(model.device), train=False)
+        tot += loss.item()
+        cnt += 1
+    t = torch.tensor([tot, cnt], device=model.device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t)
+    return (t[0] / t[1].clamp_min(1)).item()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print_arguments(args)
+    if args.gradient_accumulation_steps != 1:
+        raise NotImplementedError("gradient_accumulation_steps != 1 is outside the hot path")
+    if args.fine_tune_layers is not None or args.ft_full:
+        raise NotImplementedError("--fine_tune_layers / --ft_full: the engine adapts all encoder layers")
+    processor = get_processor(args.base_model, args.language, args.task, args.timestamps, args.local_files_only)
+    ds_kw = dict(processor=processor, modal=args.modal, modal_ch=args.eeg_ch, sample_rate=args.sampling_rate,
+                 orig_sample_rate=args.orig_sample_rate, language=args.language, filter_dataset=args.filter_dataset,
+                 timestamps=args.timestamps, min_duration=args.min_audio_len, max_duration=args.max_audio_len)
+    train_dataset = CustomDataset(data_list_path=args.train_data, mode="train", combine_sentences=args.combine_sentences,
+                                  split_sentences=args.split_sentences, augment_config_path=args.augment_config_path,
+                                  **ds_kw)
+    test_dataset = CustomDataset(data_list_path=args.test_data, mode="val", **ds_kw)
+    if args.data_ratio is not None:
+        train_dataset.data_list = get_part_of_dataset(train_dataset.data_list, args.data_ratio)
+    print(f"train samples: {len(train_dataset)}, eval samples: {len(test_dataset)}")
+    data_collator = DataCollatorSpeechSeq2SeqWithPadding(processor=processor)
+
+    # one process per GPU (reference :115-122: WORLD_SIZE / LOCAL_RANK)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK") or 0)
+    ddp = world != 1 and args.device != "cpu"
+    device_map = {"": local} if ddp else args.device
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    print(f"device map :{device_map}")
+    model = WhisperForConditionalGeneration.from_pretrained(args.base_model, load_in_8bit=args.use_8bit,
+                                                            device_map=device_map, local_files_only=args.local_files_only)
+    print(f"model device {model.device}")
+    eeg_ch = args.lora_eeg_ch if args.lora_eeg_ch is not None else args.eeg_ch
+    d_model = model.model.encoder.conv2.in_channels
+    torch.manual_seed(42)
+    conv1 = projection_module(config_name=args.config_name, meg_ch=eeg_ch, d_model=d_model).to(model.device)
+    model.model.encoder.set_input_embeddings(conv1)
+    if args.lora_model is not None:
+        model = PeftModel.from_pretrained(model, args.lora_model, local_files_only=args.local_files_only).merge_and_unload()
+        if args.lora_eeg_ch != args.eeg_ch:
+            conv1 = projection_module(config_name=args.config_name, meg_ch=args.eeg_ch, d_model=d_model).to(model.device)
+            model.model.encoder.set_input_embeddings(conv1)
+    model.config.forced_decoder_ids = None
+    model.config.suppress_tokens = []
+    model = prepare_model_for_kbit_training(model)
+    model.model.encoder.conv1.register_forward_hook(make_inputs_require_grad)
+    for p in model.parameters():
+        p.requires_grad = False
+
+    if args.resume_from_checkpoint:
+        print("Loading adapters from checkpoint.")
+        model = PeftModel.from_pretrained(model, args.resume_from_checkpoint, is_trainable=True)
+        for n in ("model.encoder.conv1", "model.encoder.conv2"):
+            for p in model.model.get_submodule(n).parameters():
+                p.requires_grad = True
+    else:
+        prefixes = ["model.encoder"]
+        suffixes = ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"]
+        target_modules = match_modules_string(model.named_modules(), prefixes, suffixes)
+        modules_to_save = ["model.encoder.conv1", "model.encoder.conv2"]
+        print("target_modules", target_modules)
+        print("modules_to_save", modules_to_save)
+        if args.use_adalora:
+            config = AdaLoraConfig(init_r=12, target_r=4, beta1=0.85, beta2=0.85, tinit=200, tfinal=1000, deltaT=10,
+                                   lora_alpha=32, lora_dropout=0.1, orth_reg_weight=0.5, target_modules=target_modules,
+                                   modules_to_save=modules_to_save)
+        else:
+            config = LoraConfig(r=32, lora_alpha=64, target_modules=target_modules, lora_dropout=0.05, bias="none",
+                                modules_to_save=modules_to_save)
+        model = get_peft_model(model, config)
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    print(f"Total trainable parameters: {trainable}")
+    frozen = set(match_modules(model.named_parameters(), [""], [""], ["original_module"]))
+    for name, p in model.named_parameters():
+        if name in frozen:
+            p.requires_grad = False
+    model.print_trainable_parameters()
+
+    base = args.base_model[:-1] if args.base_model.endswith("/") else args.base_model
+    output_dir = os.path.join(args.output_dir, os.path.basename(base).replace(":", "_"))
+    os.makedirs(output_dir, exist_ok=True)
+    B = args.per_device_train_batch_size
+    steps_per_epoch = math.ceil(math.ceil(len(train_dataset) / world) / B)
+    total_steps = steps_per_epoch * args.num_train_epochs
+    if args.max_steps > 0:
+        total_steps = min(total_steps, args.max_steps)
+    whisper = model.model
+    whisper.train_cfg = TrainCfg(lr=args.learning_rate, warmup_steps=args.warmup_steps, total_steps=total_steps,
+                                 fp16_scaler=args.fp16)
+    whisper.config.use_cache = False
+    eng = whisper.engine()
+    eng.drop_seed = 42 + rank
+    reducer = GradReducer(eng.G) if ddp else None
+
+    step, best, t_log, n_log = 0, float("inf"), time.time(), 0
+    log_path = os.path.join(output_dir, "train_log.jsonl")
+    done = False
+    for epoch in range(args.num_train_epochs):
+        idx = shard_indices(len(train_dataset), epoch, rank, world)
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(train_dataset, idx), batch_size=B, shuffle=False,
+                                             num_workers=args.num_workers, collate_fn=data_collator, drop_last=False,
+                                             pin_memory=True)
+        for batch in loader:
+            x = batch["input_features"].to(whisper.device, non_blocking=True)
+            y = batch["labels"].to(whisper.device, non_blocking=True)
+            if reducer is None:
+                loss = eng.train_step(x, y)
+            else:
+                loss = eng.train_step(x, y, on_ready=reducer.on_ready, reduce_fn=reducer.finish)
+            step += 1
+            n_log += x.shape[0]
+            if step % args.logging_steps == 0 and rank == 0:
+                dt = time.time() - t_log
+                rec = {"step": step, "epoch": round(step / steps_per_epoch, 3), "loss": round(loss.item(), 5),
+                       "samples_per_s": round(world * n_log / dt, 2), "loss_scale": eng.loss_scale_dev.item()}
+                print(json.dumps(rec), flush=True)
+                with open(log_path, "a") as f:
+                    f.write(json.dumps(rec) + "\n")
+                t_log, n_log = time.time(), 0
+            if step % args.eval_steps == 0:
+                ev = evaluate_loss(whisper, test_dataset, data_collator, args.per_device_eval_batch_size, rank, world,
+                                   args.num_workers)
+                if rank == 0:
+                    print(json.dumps({"step": step, "eval_loss": round(ev, 5)}), flush=True)
+                    if ev < best and step % args.save_steps == 0:   # save only on a new best eval loss
+                        model.save_pretrained(os.path.join(output_dir, f"checkpoint-{step}"))
+                best = min(best, ev)
+            if step >= total_steps:
+                done = True
+                break
+        if done:
+            break
+    if rank == 0:
+        model.save_pretrained(os.path.join(output_dir, "checkpoint-final"))
+        print(f"saved {os.path.join(output_dir, 'checkpoint-final')}")
+    if ddp:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

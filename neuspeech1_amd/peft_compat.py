@@ -1,0 +1,175 @@
+"""The slice of `peft` the reference uses (finetune.py:13,153-154,171,185,205-212; evaluation.py:88-89;
+merge_lora.py:43-44), re-stated for the HIP engine: LoraConfig, get_peft_model, PeftModel.from_pretrained /
+save_pretrained / merge_and_unload, prepare_model_for_kbit_training.
+
+`peft` itself is not importable offline, so these semantics are the build's DEFINITION:
+  y = W x + b + (alpha/r) * B(A(dropout_p(x))),  A ~ kaiming_uniform(a=sqrt(5)), B = 0,
+  modules_to_save = trainable copies of encoder.conv1 / encoder.conv2,
+  merge: W <- W + (alpha/r) B A.
+Adapter files use PEFT's layout: adapter_config.json + adapter_model.safetensors with keys
+`base_model.model.<module>.lora_A.weight` / `.lora_B.weight` and `base_model.model.model.encoder.conv1.0.weight` ...
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import asdict, dataclass, field
+
+import torch
+from torch import nn
+
+from .weights import LORA_SUFFIXES
+
+
+@dataclass
+class LoraConfig:
+    r: int = 8
+    lora_alpha: float = 8
+    target_modules: list = field(default_factory=list)
+    lora_dropout: float = 0.0
+    bias: str = "none"
+    modules_to_save: list = field(default_factory=list)
+    peft_type: str = "LORA"
+
+
+class AdaLoraConfig:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("AdaLoRA (finetune.py --use_adalora=True) is not on the MI355X hot path yet: "
+                                  "pass --use_adalora=False (LoRA r=32, alpha=64, dropout 0.05)")
+
+
+def prepare_model_for_kbit_training(model):
+    """peft freezes every parameter and upcasts half params; the engine keeps fp32 masters already."""
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+def _expected_targets(model):
+    names = []
+    for i in range(len(model.model.encoder.layers)):
+        for suf in LORA_SUFFIXES:
+            names.append(f"model.encoder.layers.{i}." + (suf if suf.startswith("fc") else f"self_attn.{suf}"))
+    return names
+
+
+class _Base(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+
+class PeftModel(nn.Module):
+    def __init__(self, model, config: LoraConfig, _inject=True):
+        super().__init__()
+        self.base_model = _Base(model)
+        self.peft_config = {"default": config}
+        if _inject:
+            self._inject(model, config)
+
+    # -- construction
+    @staticmethod
+    def _inject(model, config: LoraConfig):
+        want = set(_expected_targets(model))
+        if set(config.target_modules) != want:
+            raise NotImplementedError("the HIP engine carries LoRA on ALL encoder q/k/v/out/fc1/fc2 modules "
+                                      f"({len(want)} names); got {len(config.target_modules)} target modules")
+        if config.r % 16:
+            raise NotImplementedError("LoRA rank must be a multiple of 16 (MFMA K granularity)")
+        dev = model.device
+        for name in config.target_modules:
+            lin = model.get_submodule(name)
+            a = nn.Linear(lin.in_features, config.r, bias=False, device=dev)
+            b = nn.Linear(config.r, lin.out_features, bias=False, device=dev)
+            nn.init.kaiming_uniform_(a.weight, a=math.sqrt(5))
+            nn.init.zeros_(b.weight)
+            lin.lora_A = nn.ModuleDict({"default": a})
+            lin.lora_B = nn.ModuleDict({"default": b})
+            lin.weight.requires_grad = False
+            if lin.bias is not None:
+                lin.bias.requires_grad = False
+        for name in config.modules_to_save or []:
+            for p in model.get_submodule(name).parameters():
+                p.requires_grad = True
+        model._peft = config
+        model._engine = None
+
+    @classmethod
+    def from_pretrained(cls, model, path, is_trainable=False, local_files_only=True, **_):
+        with open(os.path.join(path, "adapter_config.json")) as f:
+            raw = json.load(f)
+        cfg = LoraConfig(r=raw["r"], lora_alpha=raw["lora_alpha"], target_modules=raw["target_modules"],
+                         lora_dropout=raw.get("lora_dropout", 0.0), bias=raw.get("bias", "none"),
+                         modules_to_save=raw.get("modules_to_save") or [])
+        pm = cls(model, cfg)
+        from safetensors.torch import load_file
+        sd = load_file(os.path.join(path, "adapter_model.safetensors"))
+        own = dict(pm.named_parameters())
+        for k, v in sd.items():
+            kk = k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+            own[kk].data.copy_(v.to(own[kk].device))
+        if not is_trainable:
+            for p in pm.parameters():
+                p.requires_grad = False
+        model._engine = None
+        return pm
+
+    def save_pretrained(self, path, **_):
+        os.makedirs(path, exist_ok=True)
+        cfg = self.peft_config["default"]
+        with open(os.path.join(path, "adapter_config.json"), "w") as f:
+            json.dump(asdict(cfg), f, indent=1)
+        sd = {}
+        for k, v in self.named_parameters():
+            if ".lora_" in k:
+                sd[k.replace(".default", "")] = v.detach().contiguous().cpu()
+            elif any(k.startswith("base_model.model." + m + ".") for m in (cfg.modules_to_save or [])):
+                sd[k] = v.detach().contiguous().cpu()
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(path, "adapter_model.safetensors"))
+
+    # -- use
+    @property
+    def model(self):
+        return self.base_model.model
+
+    @property
+    def config(self):
+        return self.model.config
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def forward(self, *a, **k):
+        return self.model(*a, **k)
+
+    def generate(self, *a, **k):
+        return self.model.generate(*a, **k)
+
+    def engine(self):
+        return self.model.engine()
+
+    def print_trainable_parameters(self):
+        tr = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        al = sum(p.numel() for p in self.parameters())
+        print(f"trainable params: {tr:,d} || all params: {al:,d} || trainable%: {100 * tr / al:.4f}")
+
+    def merge_and_unload(self):
+        """W <- W + (alpha/r) B A on every adapted Linear, adapters removed; returns the bare model."""
+        model = self.model
+        cfg = self.peft_config["default"]
+        scale = cfg.lora_alpha / cfg.r
+        with torch.no_grad():
+            for name in cfg.target_modules:
+                lin = model.get_submodule(name)
+                lin.weight.add_(scale * lin.lora_B["default"].weight.float() @ lin.lora_A["default"].weight.float())
+                del lin.lora_A, lin.lora_B
+        model._peft = None
+        model._engine = None
+        return model
+
+
+def get_peft_model(model, config: LoraConfig) -> PeftModel:
+    return PeftModel(model, config)

@@ -1,0 +1,81 @@
+"""GPU: BASELINE configs[0]-style plumbing through the drop-in entry points: finetune.py (LoRA + conv-stem training
+steps, eval loss, adapter checkpoint in PEFT layout), then evaluation.py (merge_and_unload + beam-5 decode with
+repetition penalty / no-repeat-ngram, and the teacher-forced branch) on a synthetic MEG list."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_finetune_then_evaluation_end_to_end(dev, tmp_path):
+    import evaluation
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 12, ch_file=24, name="toyset", seed=1, min_len=120, max_len=520)
+    out = str(tmp_path / "out")
+    common = ["--modal=eeg", "--eeg_ch=20", "--sampling_rate=200", "--timestamps=False", "--max_audio_len=2.0",
+              "--language=Dutch", "--num_workers=0"]
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}",
+                   "--orig_sample_rate=200", "--use_adalora=False", "--fp16=True", "--num_train_epochs=2",
+                   "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
+                   "--eval_steps=2", "--save_steps=2", "--warmup_steps=2", "--learning_rate=1e-3",
+                   "--augment_config_path=None", "--max_steps=6"] + common)
+    ck = os.path.join(out, "synthetic_tiny", "checkpoint-final")
+    assert os.path.exists(os.path.join(ck, "adapter_config.json")) and os.path.exists(os.path.join(ck, "adapter_model.safetensors"))
+    logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_tiny", "train_log.jsonl"))]
+    assert len(logs) == 6 and logs[-1]["loss"] < logs[0]["loss"], logs
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(ck, "adapter_model.safetensors"))
+    assert "base_model.model.model.encoder.layers.0.self_attn.q_proj.lora_A.weight" in sd
+    assert "base_model.model.model.encoder.conv1.0.weight" in sd and sd["base_model.model.model.encoder.conv1.0.weight"].shape == (256, 20, 3)
+    assert sd["base_model.model.model.encoder.layers.1.fc2.lora_B.weight"].abs().sum() > 0   # B left its zero init
+    evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                     "--max_new_tokens=8"] + common)
+    res = json.load(open(os.path.join(ck, "formal_test_resultsno_post_processing.json")))
+    assert res["samples"] == 12 and res["generated_tokens_per_s"] > 0
+    assert len(open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).readlines()) == 12
+    evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                     "--teacher_forcing=True"] + common)
+    res = json.load(open(os.path.join(ck, "formal_test_resultsno_post_processing_tf.json")))
+    assert 0.0 <= res["teacher_forced_token_accuracy"] <= 1.0
+
+
+def test_module_api_loss_backward_matches_engine(dev):
+    """`.loss.backward()` through the nn.Module surface yields the engine's (unscaled) gradients; merged weights
+    reproduce the adapted forward (merge_and_unload, evaluation.py:88-89)."""
+    from neuspeech1_amd.peft_compat import LoraConfig, get_peft_model
+    from neuspeech1_amd.weights import TINY, synth_batch
+    from utils.load_model import WhisperForConditionalGeneration, match_modules_string
+    from utils.model_utils import projection_module
+    torch.manual_seed(0)
+    model = WhisperForConditionalGeneration.from_pretrained("synthetic:tiny", device_map="auto")
+    model.model.encoder.set_input_embeddings(projection_module(config_name="base", meg_ch=20, d_model=256).to(model.device))
+    for p in model.parameters():
+        p.requires_grad = False
+    t = match_modules_string(model.named_modules(), ["model.encoder"], ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"])
+    pm = get_peft_model(model, LoraConfig(r=32, lora_alpha=64, target_modules=t, lora_dropout=0.0,
+                                          modules_to_save=["model.encoder.conv1", "model.encoder.conv2"]))
+    with torch.no_grad():
+        for n, p in pm.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.02)
+    x, labels = synth_batch(TINY, 2, 9)
+    x, labels = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    pm.train()
+    out = pm(input_features=x, labels=labels)
+    out.loss.backward()
+    g = dict(pm.named_parameters())["base_model.model.model.encoder.layers.0.fc1.lora_A.default.weight"].grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    cb = dict(pm.named_parameters())["base_model.model.model.encoder.conv2.bias"].grad
+    eng = model.engine()
+    torch.testing.assert_close(cb, eng.gview("model.encoder.conv2.bias") / eng.loss_scale_dev)
+    pm.eval()
+    with torch.no_grad():
+        a = pm(input_features=x, labels=labels)
+        merged = pm.merge_and_unload()
+        b = merged(input_features=x, labels=labels)
+    assert abs(a.loss.item() - b.loss.item()) < 5e-3
+    torch.testing.assert_close(a.logits.float(), b.logits.float(), atol=3e-2, rtol=3e-2)

@@ -162,3 +162,79 @@ if __name__ == "__main__":
         lora_golden(TINY, "tiny", B=2)
     if "decode" in what:
         decode_golden(TINY, "tiny", B=3, new_tokens=24)
+
+
+def reader_golden():
+    """G6: run the REFERENCE reader / collator / matchers (imported from /root/reference with the four absent
+    third-party modules stubbed; none is touched on the EEG path) on seeded synthetic files."""
+    import json
+    import tempfile
+    import types
+    for name in ("jsonlines", "librosa", "soundfile", "zhconv", "matplotlib", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["zhconv"].convert = lambda t, _: t
+
+    class _JL:
+        def __init__(self, path, mode="r"):
+            self.f = open(path, mode)
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            self.f.close()
+        def __iter__(self):
+            return (json.loads(l) for l in self.f if l.strip())
+        def write(self, obj):
+            self.f.write(json.dumps(obj) + "\n")
+    sys.modules["jsonlines"].open = lambda p, mode="r": _JL(p, mode)
+    sys.path.insert(0, REF)
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[m]
+    import importlib
+    ref_reader = importlib.import_module("utils.reader")
+    ref_data = importlib.import_module("utils.data_utils")
+    from neuspeech1_amd.synthetic import SyntheticProcessor
+    from neuspeech1_amd.weights import WHISPER_BASE
+    proc = SyntheticProcessor(WHISPER_BASE)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        cases = [("gwilliams", 224, 208), ("schoffelen", 301, 273), ("other", 100, 208)]
+        for name, ch_file, modal_ch in cases:
+            os.makedirs(os.path.join(td, name), exist_ok=True)
+            rows = []
+            for n in (700, 6000, 7321):
+                rng = np.random.default_rng(ch_file * 100000 + n)
+                x = rng.standard_normal((ch_file, n))
+                p = os.path.join(td, name, f"s{n}.npy")
+                np.save(p, x)
+                rows.append({"eeg": {"path": p}, "sentence": f"hello {name} {n}", "language": "English", "duration": n / 200})
+            jl = os.path.join(td, f"{name}.jsonl")
+            with open(jl, "w") as f:
+                for r in rows:
+                    f.write(json.dumps(r) + "\n")
+            ds = ref_reader.CustomDataset(data_list_path=jl, processor=proc, modal="eeg", modal_ch=modal_ch, mode="val",
+                                          sample_rate=200, orig_sample_rate=200, language="English", timestamps=False,
+                                          min_duration=0.5, max_duration=30)
+            items = [ds[i] for i in range(len(ds))]
+            for i, it in enumerate(items):
+                a = it["input_features"][0]
+                nz = np.nonzero(np.abs(a).sum(0))[0]
+                out[f"{name}.{i}.shape"] = np.array(a.shape)
+                out[f"{name}.{i}.sum"] = np.float64(a.sum())
+                out[f"{name}.{i}.abs"] = np.float64(np.abs(a).sum())
+                out[f"{name}.{i}.last_nz"] = np.int64(nz[-1])
+                out[f"{name}.{i}.rows_nz"] = np.int64((np.abs(a).sum(1) > 0).sum())
+                out[f"{name}.{i}.labels"] = np.array(it["labels"])
+            batch = ref_data.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)
+            out[f"{name}.batch_dtype"] = np.array(str(batch["input_features"].dtype))
+            out[f"{name}.batch_sum"] = np.float64(batch["input_features"].double().sum().item())
+            out[f"{name}.batch_labels"] = batch["labels"].numpy()
+    np.savez_compressed(os.path.join(OUT, "reader.npz"), **out)
+    print("reader golden:", len(out), "entries")
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[m]
+    sys.path.remove(REF)
+
+
+if __name__ == "__main__" and "reader" in (sys.argv[1:] or ["reader"]):
+    reader_golden()

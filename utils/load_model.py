@@ -1,0 +1,371 @@
+"""`WhisperForConditionalGeneration` with the reference's surface (reference utils/load_model.py:327-1401,
+used at finetune.py:18,127-148 and, as the stock HF class, at evaluation.py:72-86) on the MI355X engine.
+
+The nn.Module tree only CARRIES parameters under HuggingFace's dotted names (LoRA target selection is by name,
+finetune.py:189-198); forward / backward / generate run in libneuspeech_hip through
+neuspeech1_amd.engine.MegWhisperEngine.  There is no CPU fallback: without a GPU + the HIP library, forward raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from neuspeech1_amd.weights import TINY, WHISPER_BASE, WHISPER_LARGE_V2, WhisperDims, make_state_dict
+
+
+# ----------------------------------------------------------------------------- name matchers (reference :48-100)
+def match_modules_string(named_modules, start_prefixes, end_suffixes, mid_prefixes=[]):
+    """names that start with any prefix, (contain any mid-fix when given) and end with any suffix, in iteration order."""
+    out = []
+    for name, _ in named_modules:
+        if not any(name.startswith(p) for p in start_prefixes):
+            continue
+        if mid_prefixes and not any(m in name for m in mid_prefixes):
+            continue
+        if any(name.endswith(s) for s in end_suffixes):
+            out.append(name)
+    return out
+
+
+def match_modules(named_modules, prefix_list, suffix_list, mid_fix_list=[""]):
+    """regex form ^(prefix).*(mid).*(suffix)$; a name is appended once per matching (prefix, suffix) pair."""
+    out = []
+    for name, _ in named_modules:
+        for prefix in prefix_list:
+            for suffix in suffix_list:
+                for mid in mid_fix_list:
+                    if re.match(re.compile(rf"^({prefix}).*({mid}).*({suffix})$"), name):
+                        out.append(name)
+                        break
+    return out
+
+
+# ----------------------------------------------------------------------------- parameter-carrying module tree
+class WhisperAttention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class WhisperEncoderLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = WhisperAttention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class WhisperDecoderLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = WhisperAttention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.encoder_attn = WhisperAttention(d)
+        self.encoder_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class WhisperEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.d_model
+        self.conv1 = nn.Conv1d(cfg.num_mel_bins, d, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(cfg.max_source_positions, d)
+        self.layers = nn.ModuleList([WhisperEncoderLayer(d, cfg.encoder_ffn_dim) for _ in range(cfg.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+
+    def get_input_embeddings(self):
+        return self.conv1
+
+    def set_input_embeddings(self, value: nn.Module):
+        self.conv1 = value
+
+
+class WhisperDecoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.d_model
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, d)
+        self.embed_positions = nn.Embedding(cfg.max_target_positions, d)
+        self.layers = nn.ModuleList([WhisperDecoderLayer(d, cfg.decoder_ffn_dim) for _ in range(cfg.decoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class WhisperModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.encoder = WhisperEncoder(cfg)
+        self.decoder = WhisperDecoder(cfg)
+
+
+_SYNTH = {"tiny": TINY, "base": WHISPER_BASE, "large-v2": WHISPER_LARGE_V2}
+
+
+def _cfg_from_dims(dm: WhisperDims) -> SimpleNamespace:
+    return SimpleNamespace(
+        vocab_size=dm.vocab, num_mel_bins=80, d_model=dm.d, encoder_layers=dm.enc_layers, decoder_layers=dm.dec_layers,
+        encoder_attention_heads=dm.heads, decoder_attention_heads=dm.heads, encoder_ffn_dim=dm.ffn,
+        decoder_ffn_dim=dm.ffn, max_source_positions=dm.src_pos, max_target_positions=dm.tgt_pos,
+        pad_token_id=dm.pad_id, bos_token_id=dm.bos_id, eos_token_id=dm.eos_id, decoder_start_token_id=dm.start_id,
+        forced_decoder_ids=None, suppress_tokens=[], begin_suppress_tokens=[], use_cache=True, max_length=dm.tgt_pos)
+
+
+class Seq2SeqLMOutput(dict):
+    __getattr__ = dict.get
+
+
+class WhisperForConditionalGeneration(nn.Module):
+    base_model_prefix = "model"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = WhisperModel(config)
+        self.proj_out = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.proj_out.weight = self.model.decoder.embed_tokens.weight    # tied (reference :947)
+        self._engine = None
+        self._peft = None          # set by neuspeech1_amd.peft_compat.get_peft_model
+        self.train_cfg = None
+        self.train(False)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, path, load_in_8bit=False, device_map=None, local_files_only=True, **_):
+        """`path`: a directory with config.json + model.safetensors (HF names), or `synthetic:{tiny|base|large-v2}[:seed]`
+        for the documented seeded random init (no pretrained weights exist offline)."""
+        if load_in_8bit:
+            raise NotImplementedError("8-bit loading is outside the MI355X hot path")
+        if isinstance(path, str) and path.startswith("synthetic:"):
+            parts = path.split(":")
+            dm = _SYNTH[parts[1]]
+            seed = int(parts[2]) if len(parts) > 2 else 42
+            model = cls(_cfg_from_dims(dm))
+            sd = {k: torch.from_numpy(v) for k, v in make_state_dict(dm, seed).items() if "conv1." not in k}
+            model.load_state_dict(sd, strict=False)
+        else:
+            with open(os.path.join(path, "config.json")) as f:
+                raw = json.load(f)
+            cfg = _cfg_from_dims(WHISPER_BASE)
+            for k, v in raw.items():
+                setattr(cfg, k, v)
+            model = cls(cfg)
+            from safetensors.torch import load_file
+            sd = load_file(os.path.join(path, "model.safetensors"))
+            own = model.state_dict()
+            sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+            model.load_state_dict(sd, strict=False)
+        dev = _resolve_device(device_map)
+        return model.to(dev)
+
+    def save_pretrained(self, save_directory, **_):
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {k: v for k, v in vars(self.config).items() if isinstance(v, (int, float, str, list, type(None), bool))}
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+        from safetensors.torch import save_file
+        sd = {k: v.detach().contiguous().cpu() for k, v in self.state_dict().items() if k != "proj_out.weight"}
+        save_file(sd, os.path.join(save_directory, "model.safetensors"))
+
+    # ------------------------------------------------------------------ HF-style accessors
+    @property
+    def device(self):
+        return self.model.decoder.embed_tokens.weight.device
+
+    def get_encoder(self):
+        return self.model.encoder
+
+    def get_decoder(self):
+        return self.model.decoder
+
+    def get_input_embeddings(self):
+        return self.model.decoder.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.proj_out
+
+    def post_init(self):
+        pass
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_engine(self):
+        """call after editing frozen weights in place"""
+        self._engine = None
+
+    # ------------------------------------------------------------------ engine
+    def dims(self) -> WhisperDims:
+        c, conv = self.config, self.model.encoder.conv1
+        first = conv[0] if isinstance(conv, nn.Sequential) else conv
+        return WhisperDims(d=c.d_model, heads=c.encoder_attention_heads, ffn=c.encoder_ffn_dim,
+                           enc_layers=c.encoder_layers, dec_layers=c.decoder_layers, vocab=c.vocab_size,
+                           src_pos=c.max_source_positions, tgt_pos=c.max_target_positions, ch=first.in_channels,
+                           pad_id=c.pad_token_id, bos_id=c.bos_token_id, eos_id=c.eos_token_id,
+                           start_id=c.decoder_start_token_id)
+
+    def engine(self):
+        """Build (once) the HIP engine from the current parameters; trainable parameters are re-pointed at the
+        engine's flat fp32 buffer so optimizer updates and state_dict() see the same storage."""
+        if self._engine is not None:
+            return self._engine
+        from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+        if self.device.type != "cuda":
+            raise RuntimeError("the MI355X engine needs the model on a GPU (no CPU fallback for the product path)")
+        conv = self.model.encoder.conv1
+        if not isinstance(conv, nn.Sequential):
+            raise RuntimeError("install the MEG front-end first: model.model.encoder.set_input_embeddings("
+                               "projection_module('base', meg_ch=..., d_model=...))")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        lora, lora_sd = None, None
+        if self._peft is not None:
+            pc = self._peft
+            lora = LoraSpec(r=pc.r, alpha=float(pc.lora_alpha), dropout=float(pc.lora_dropout))
+            lora_sd = {k.replace(".default", ""): v for k, v in sd.items() if ".lora_" in k}
+        eng = MegWhisperEngine(self.dims(), sd, lora=lora, lora_sd=lora_sd, train_cfg=self.train_cfg or TrainCfg(),
+                               device=self.device)
+        self._engine = eng
+        self._tie_trainables(eng)
+        return eng
+
+    def _tie_trainables(self, eng):
+        enc = self.model.encoder
+        for name, mod in (("conv1.0", enc.conv1[0]), ("conv1.2", enc.conv1[2]), ("conv2", enc.conv2)):
+            mod.weight.data = eng.conv_weight(name)
+            mod.bias.data = eng.pview(f"model.encoder.{name}.bias")
+        if self._peft is None:
+            return
+        d, f, r = eng.dims.d, eng.dims.ffn, eng.r
+        for i, layer in enumerate(enc.layers):
+            p = f"model.encoder.layers.{i}."
+            A = eng.pview(p + "self_attn.qkv.lora_A").view(3, r, d)
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                m = getattr(layer.self_attn, nm)
+                m.lora_A["default"].weight.data = A[j]
+                m.lora_B["default"].weight.data = eng.pview(p + f"self_attn.{nm}.lora_B").view(d, r)
+            for nm, m, no, ki in (("self_attn.out_proj", layer.self_attn.out_proj, d, d), ("fc1", layer.fc1, f, d),
+                                  ("fc2", layer.fc2, d, f)):
+                m.lora_A["default"].weight.data = eng.pview(p + nm + ".lora_A").view(r, ki)
+                m.lora_B["default"].weight.data = eng.pview(p + nm + ".lora_B").view(no, r)
+
+    # ------------------------------------------------------------------ forward / generate
+    def forward(self, input_features=None, attention_mask=None, decoder_input_ids=None, labels=None, **_):
+        """reference utils/load_model.py:976-1070: returns an object with .loss (0-d) and .logits (B, L, V)."""
+        eng = self.engine()
+        eng.refresh_operands()   # trainables may have been stepped by an external torch optimizer
+        x = input_features.to(self.device, torch.float32).contiguous()
+        if labels is not None:
+            labels = labels.to(self.device)
+        if decoder_input_ids is not None:
+            decoder_input_ids = decoder_input_ids.to(self.device)
+        want_grad = self.training and torch.is_grad_enabled() and labels is not None
+        if want_grad:
+            loss = _TrainStepFn.apply(self, x, labels, *self._trainable_tensors())
+            logits = None
+        else:
+            loss, logits = eng.forward(x, labels, decoder_input_ids=decoder_input_ids, train=False)
+            loss = loss.clone().reshape(()) if loss is not None else None
+            logits = logits.clone()
+        return Seq2SeqLMOutput(loss=loss, logits=logits)
+
+    def _trainable_tensors(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    @torch.no_grad()
+    def generate(self, input_features=None, inputs=None, do_sample=False, num_beams=1, repetition_penalty=1.0,
+                 no_repeat_ngram_size=0, decoder_input_ids=None, max_new_tokens=None, max_length=None,
+                 length_penalty=1.0, suppress_tokens=None, begin_suppress_tokens=None, eos_token_id=None,
+                 pad_token_id=None, sequence_bias=None, **_):
+        """evaluation.py:370-386 call shape; returns prompt + generated ids (B, <= max_length) int64."""
+        if do_sample:
+            raise NotImplementedError("sampling is outside the hot path (the reference decodes with do_sample=False)")
+        if sequence_bias:
+            raise NotImplementedError("sequence_bias (--add_sequence_bias) is outside the hot path")
+        from neuspeech1_amd.generate import Generator
+        eng = self.engine()
+        eng.refresh_operands()
+        x = (input_features if input_features is not None else inputs).to(self.device, torch.float32).contiguous()
+        c = self.config
+        if decoder_input_ids is None:
+            decoder_input_ids = torch.full((x.shape[0], 1), c.decoder_start_token_id, dtype=torch.int64)
+        prompt = decoder_input_ids.to(self.device, torch.int64).contiguous()
+        limit = max_length or getattr(c, "max_length", None) or c.max_target_positions
+        new = max_new_tokens if max_new_tokens is not None else limit - prompt.shape[1]
+        sup = suppress_tokens if suppress_tokens is not None else (c.suppress_tokens or [])
+        bsup = begin_suppress_tokens if begin_suppress_tokens is not None else (getattr(c, "begin_suppress_tokens", None) or [])
+        return Generator(eng).generate(x, prompt, num_beams=num_beams, max_new_tokens=new,
+                                       repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
+                                       suppress_tokens=list(sup), begin_suppress_tokens=list(bsup),
+                                       length_penalty=length_penalty, eos_id=eos_token_id, pad_id=pad_token_id)
+
+
+def _resolve_device(device_map):
+    if device_map in (None, "auto", "cuda"):
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if isinstance(device_map, dict):
+        return torch.device("cuda", int(device_map[""]))
+    return torch.device(device_map)
+
+
+class _TrainStepFn(torch.autograd.Function):
+    """`.loss.backward()` compatibility: one autograd node around the engine's explicit forward / backward.
+    Gradients of the trainable parameters are read out of the engine's flat gradient buffer (unscaled)."""
+
+    @staticmethod
+    def forward(ctx, model, x, labels, *params):
+        eng = model.engine()
+        eng.zero_grad()
+        loss, _ = eng.forward(x, labels, train=True, compute_grad=True)
+        ctx.model, ctx.params = model, params
+        return loss.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        model, eng = ctx.model, ctx.model.engine()
+        eng.backward()
+        scale = g / eng.loss_scale_dev
+        grads = []
+        gmap = model._grad_views(eng)
+        for p in ctx.params:
+            v = gmap.get(p.data_ptr())
+            grads.append(None if v is None else (v * scale))
+        return (None, None, None, *grads)
+
+
+def _grad_views(self, eng):
+    """parameter storage pointer -> view of the engine gradient buffer with the parameter's shape"""
+    out = {}
+    enc = self.model.encoder
+    for name, mod in (("conv1.0", enc.conv1[0]), ("conv1.2", enc.conv1[2]), ("conv2", enc.conv2)):
+        out[mod.weight.data_ptr()] = eng.conv_weight_grad(name)
+        out[mod.bias.data_ptr()] = eng.gview(f"model.encoder.{name}.bias")
+    if self._peft is not None:
+        d, f, r = eng.dims.d, eng.dims.ffn, eng.r
+        for i, layer in enumerate(enc.layers):
+            p = f"model.encoder.layers.{i}."
+            A = eng.gview(p + "self_attn.qkv.lora_A").view(3, r, d)
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                m = getattr(layer.self_attn, nm)
+                out[m.lora_A["default"].weight.data_ptr()] = A[j]
+                out[m.lora_B["default"].weight.data_ptr()] = eng.gview(p + f"self_attn.{nm}.lora_B").view(d, r)
+            for nm, m, no, ki in (("self_attn.out_proj", layer.self_attn.out_proj, d, d), ("fc1", layer.fc1, f, d),
+                                  ("fc2", layer.fc2, d, f)):
+                out[m.lora_A["default"].weight.data_ptr()] = eng.gview(p + nm + ".lora_A").view(r, ki)
+                out[m.lora_B["default"].weight.data_ptr()] = eng.gview(p + nm + ".lora_B").view(no, r)
+    return out
+
+
+WhisperForConditionalGeneration._grad_views = _grad_views
