@@ -413,6 +413,7 @@ void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
 }  // namespace
 
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
+int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -457,7 +458,10 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
   const size_t lds = 2 * TILE_BYTES + 2 * (size_t)bn * BK * 2;   // BN=128: 64 KiB (= the fp32 epilogue tile)
   hipStream_t st = (hipStream_t)stream;
-  if (tn) {
+  if (tn && g_use_ring && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
+      d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 && d->M >= 8 && d->N >= 8) {
+    ns_gemm_tn_launch(d, st);   // row-major staging + ds_read_b64_tr_b16 fragments
+  } else if (tn) {
     dim3 grid(tiles, 1, d->splits);
     if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
   } else if (skinny) {

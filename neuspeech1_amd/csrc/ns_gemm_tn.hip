@@ -1,0 +1,195 @@
+// Weight-gradient GEMM, TN form: C[i][j] (+)= alpha * sum_m A[m][i] * B[m][j]   (dW = dY^T X).
+// Both operands are reduction-major in HBM.  They are staged ROW-MAJOR into LDS with 16-B coalesced loads
+// (a wave covers 4 rows x 256 B) and the k-contiguous MFMA fragments are produced by the gfx950 transposed LDS
+// read ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of a 4-row block), so no register or
+// global-side transpose exists.  LDS row stride = 320 B for 128-column tiles / 64 B for 32-column tiles: the four
+// rows a half wave touches per transposed read then tile the 64 banks exactly (conflict-free).
+// Tiles: <128,128> (conv weight grads), <32,128> (LoRA dA: r x K), <128,32> (LoRA dB: N x r).  The reduction is split
+// over gridDim.z and accumulated with fp32 atomics in the full-rate shape (128 contiguous bytes per half wave).
+#include "ns_common.h"
+
+namespace {
+
+constexpr int BKM = 64, NTH = 256;
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v lds_s4;
+
+template <int BW> struct RowStride { static constexpr int bytes = BW == 128 ? 320 : 64; };
+
+__device__ __forceinline__ half8 tr_frag(const char* tile, int stride, int m0, int c0, int lane) {
+  // rows m0..m0+7 (two 4-row blocks), 16 columns starting at c0 + 16*(g&1); returns the 8 k-values of this lane's column
+  const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+  const char* a = tile + (m0 + 8 * (g >> 1) + q) * stride + (c0 + 16 * (g & 1) + 4 * p) * 2;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)a);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a + 4 * stride));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8, r);
+}
+
+template <int BI, int BJ, bool DROP>
+__global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SA = RowStride<BI>::bytes, SB = RowStride<BJ>::bytes;
+  constexpr int A_BYTES = BKM * SA, B_BYTES = BKM * SB;
+  // wave layout: 128x128 -> 2x2 waves of 64x64; 32x128 -> 1x4 of 32x32; 128x32 -> 4x1 of 32x32
+  constexpr int WI = BI == 128 && BJ == 128 ? 64 : 32, WJ = WI;
+  constexpr int TI = WI / 32, TJ = WJ / 32;
+  constexpr int CA = BI / 8, CB = BJ / 8;                 // 16-B chunks per row
+  constexpr int LA = BKM * CA / NTH, LB = BKM * CB / NTH;  // loads per thread per K-step (4 or 1)
+  char* const As = smem;
+  char* const Bs = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = (BI == 128 && BJ == 128) ? (wave >> 1) : (BI == 128 ? wave : 0);
+  const int wj = (BI == 128 && BJ == 128) ? (wave & 1) : (BI == 128 ? 0 : wave);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_j = (p.N + BJ - 1) / BJ;
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+  const int i0 = ti * BI, j0 = tj * BJ;
+
+  const int chunk = (((p.K + p.splits - 1) / p.splits) + BKM - 1) / BKM * BKM;
+  const int k_begin = blockIdx.z * chunk;
+  const int k_end = min(p.K, k_begin + chunk);
+  const int nsteps = (max(k_end - k_begin, 0) + BKM - 1) / BKM;
+  int seg = 0, within = k_begin;
+  if (p.am.seg_rows > 0) { seg = k_begin / p.am.seg_rows; within = k_begin - seg * p.am.seg_rows; }
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const float drop_inv = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
+  const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 4294967296.f) : 0u;
+
+  // column chunk of this thread (clamped into the valid range: redundant but in-bounds, results discarded)
+  const int ca = tid % CA, cb = tid % CB;
+  const int cola = min(i0 + ca * 8, p.M - 8), colb = min(j0 + cb * 8, p.N - 8);
+
+  uint4 ra[LA], rb[LB];
+  auto row_off = [&](const ns_rowmap& map, int rl) __attribute__((always_inline)) -> long long {
+    if (map.seg_rows > 0) {
+      int w = within + rl, s = seg;
+      if (w >= map.seg_rows) { w -= map.seg_rows; s += 1; }
+      return (long long)s * map.seg_stride + (long long)w * map.ld;
+    }
+    return (long long)(within + rl) * map.ld;
+  };
+  auto load = [&](int step) __attribute__((always_inline)) {
+    const int klen = min(BKM, k_end - k_begin - step * BKM);
+#pragma unroll
+    for (int it = 0; it < LA; ++it) {
+      const int rl = tid / CA + it * (NTH / CA);
+      ra[it] = rl < klen ? *(const uint4*)((const half_t*)p.A + row_off(p.am, rl) + cola) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < LB; ++it) {
+      const int rl = tid / CB + it * (NTH / CB);
+      uint4 v = rl < klen ? *(const uint4*)((const half_t*)p.B + row_off(p.bm, rl) + colb) : make_uint4(0, 0, 0, 0);
+      if (DROP) {
+        const uint32_t grow = (uint32_t)(k_begin + step * BKM + rl);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          half2v hv = __builtin_bit_cast(half2v, w[e]);
+          hv[0] = ns_hash3(p.drop_seed, grow, (uint32_t)(colb + 2 * e)) >= drop_thr ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
+          hv[1] = ns_hash3(p.drop_seed, grow, (uint32_t)(colb + 2 * e + 1)) >= drop_thr ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
+          w[e] = __builtin_bit_cast(uint32_t, hv);
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      rb[it] = v;
+    }
+    within += BKM;
+    if (p.am.seg_rows > 0 && within >= p.am.seg_rows) { within -= p.am.seg_rows; seg += 1; }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < LA; ++it)
+      *(uint4*)(As + buf * A_BYTES + (tid / CA + it * (NTH / CA)) * SA + ca * 16) = ra[it];
+#pragma unroll
+    for (int it = 0; it < LB; ++it)
+      *(uint4*)(Bs + buf * B_BYTES + (tid / CB + it * (NTH / CB)) * SB + cb * 16) = rb[it];
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* as = As + buf * A_BYTES;
+    const char* bs = Bs + buf * B_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      half8 af[TI], bf[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; ++a) af[a] = tr_frag(as, SA, 16 * s, wi * WI + a * 32, lane);
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) bf[b] = tr_frag(bs, SB, 16 * s, wj * WJ + b * 32, lane);
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  if (nsteps > 0) {
+    load(0);
+    store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const bool more = s + 1 < nsteps;
+      if (more) load(s + 1);
+      compute(cur);
+      if (more) store(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
+  const bool atomic32 = p.flags & NS_GEMM_ATOMIC32;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int col = j0 + wj * WJ + b * 32 + lr;
+      if (col < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i0 + wi * WI + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < p.M) {
+            float* dst = p.C32 + (long long)row * p.ldc32 + col;
+            const float v = acc[a][b][r] * alpha;
+            if (atomic32) atomicAdd(dst, v); else *dst = v;
+          }
+        }
+      }
+    }
+}
+
+template <int BI, int BJ, bool DROP>
+void launch_tn(const ns_gemm_desc* d, hipStream_t st) {
+  const int tiles = ((d->M + BI - 1) / BI) * ((d->N + BJ - 1) / BJ);
+  const size_t lds = 2 * (size_t)BKM * (RowStride<BI>::bytes + RowStride<BJ>::bytes);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)ns_gemm_tn_kernel<BI, BJ, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((ns_gemm_tn_kernel<BI, BJ, DROP>), dim3(tiles, 1, d->splits), dim3(NTH), lds, st, *d);
+}
+
+}  // namespace
+
+// called by ns_gemm() for TN descriptors whose M, N and row strides are multiples of 8 (arguments already validated)
+int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st) {
+  const bool drop = d->drop_p > 0.f;
+  if (d->M <= 96) { if (drop) launch_tn<32, 128, true>(d, st); else launch_tn<32, 128, false>(d, st); }
+  else if (d->N <= 96) { if (drop) launch_tn<128, 32, true>(d, st); else launch_tn<128, 32, false>(d, st); }
+  else { if (drop) launch_tn<128, 128, true>(d, st); else launch_tn<128, 128, false>(d, st); }
+  return 0;
+}
