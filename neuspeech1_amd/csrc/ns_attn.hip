@@ -23,55 +23,42 @@ namespace {
 
 constexpr int D = 64;
 
+// ONE LDS image per 64x64 tile serves the row reads (ds_read_b128, lane = row) AND the transposed reads
+// (ds_read_b64_tr_b16): 8-row x 32-column subtiles of 512 B, chunk XOR (row>>2)&3 (cdna guide §5.5 T10 image (a)
+// cut down to 64 columns).  Both read kinds are bank-conflict free.
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  return 1024 * (row >> 3) + 512 * (chunk >> 2) + 64 * (row & 7) + 16 * ((chunk & 3) ^ ((row >> 2) & 3));
+}
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) short4v lds_s4;
+// Transposed fragment: A[row = cb + (lane&31)][k] of v_mfma_f32_32x32x16 where the tile is stored [k][col] and the
+// OTHER operand is a 32x32 accumulator converted in place: element j of lane half h is tile row
+//   rbase + 8*(j>>2) + 4*h + (j&3)       (cdna guide §3 "accumulator as operand")
+// = two 4-row transposed reads at rows rbase+4h and rbase+8+4h.
+__device__ __forceinline__ half8 tr_frag8(const char* tile, int rbase, int cb, int lane) {
+  const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+  const int row = rbase + 4 * (g >> 1) + q;
+  const int ch = (cb >> 3) + 2 * (g & 1) + (p >> 1);
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + lds_off(row, ch) + 8 * (p & 1)));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + lds_off(row + 8, ch) + 8 * (p & 1)));
+  const short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8, r);
 }
 
 // ---- staging helpers (256 threads, tile = 64 rows x 64 halfs) ------------------
 // row-major image: thread handles 2 x 16 B
-__device__ __forceinline__ void load_rm(const half_t* __restrict__ base, long long ld, int row0, int L, uint4 r[2]) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int id = threadIdx.x + 256 * it;
-    const int row = min(row0 + (id >> 3), L - 1);
-    r[it] = *(const uint4*)(base + (long long)row * ld + (id & 7) * 8);
-  }
+__device__ __forceinline__ void load_rm(const half_t* __restrict__ base, long long ld, int row0, int L, uint4& r0, uint4& r1) {
+  const int id = threadIdx.x;
+  r0 = *(const uint4*)(base + (long long)min(row0 + (id >> 3), L - 1) * ld + (id & 7) * 8);
+  r1 = *(const uint4*)(base + (long long)min(row0 + 32 + (id >> 3), L - 1) * ld + (id & 7) * 8);
 }
-__device__ __forceinline__ void store_rm(char* lds, const uint4 r[2]) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int id = threadIdx.x + 256 * it;
-    *(uint4*)(lds + lds_off(id >> 3, id & 7)) = r[it];
-  }
+__device__ __forceinline__ void store_rm(char* lds, const uint4& r0, const uint4& r1) {
+  const int id = threadIdx.x;
+  *(uint4*)(lds + lds_off(id >> 3, id & 7)) = r0;
+  *(uint4*)(lds + lds_off(32 + (id >> 3), id & 7)) = r1;
 }
-// transposed image T[col][row-permuted]: chunk g (8 rows) of column c holds rows
-//   16*(g>>1) + 8*(j>>2) + 4*(g&1) + (j&3),  j = 0..7
-// which is the k-order v_mfma_f32_32x32x16 expects when the OTHER operand is a
-// 32x32 accumulator converted in place (cdna guide §3 "accumulator as operand").
-__device__ __forceinline__ void load_tr(const half_t* __restrict__ base, long long ld, int row0, int L, uint32_t w[8]) {
-  const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int rl = 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3);
-    const int row = min(row0 + rl, L - 1);
-    w[j] = *(const uint32_t*)(base + (long long)row * ld + 2 * q);
-  }
-}
-__device__ __forceinline__ void store_tr(char* lds, const uint32_t w[8]) {
-  const int q = threadIdx.x & 31, g = threadIdx.x >> 5;
-  uint4 lo, hi;
-  lo.x = (w[0] & 0xFFFFu) | (w[1] << 16);
-  lo.y = (w[2] & 0xFFFFu) | (w[3] << 16);
-  lo.z = (w[4] & 0xFFFFu) | (w[5] << 16);
-  lo.w = (w[6] & 0xFFFFu) | (w[7] << 16);
-  hi.x = (w[0] >> 16) | (w[1] & 0xFFFF0000u);
-  hi.y = (w[2] >> 16) | (w[3] & 0xFFFF0000u);
-  hi.z = (w[4] >> 16) | (w[5] & 0xFFFF0000u);
-  hi.w = (w[6] >> 16) | (w[7] & 0xFFFF0000u);
-  *(uint4*)(lds + lds_off(2 * q, g)) = lo;
-  *(uint4*)(lds + lds_off(2 * q + 1, g)) = hi;
-}
-
 __device__ __forceinline__ half8 cvt8(const f32x16& x, int base) {
   half8 h;
 #pragma unroll
@@ -86,7 +73,7 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* const Ks = smem;
-  char* const Vt = smem + 8192;
+  char* const Vs = smem + 8192;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
   const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
@@ -111,16 +98,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) 
   if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);  // keys beyond the block's last query are never visible
   const int ntiles = (max(kend, 0) + 63) / 64;
 
-  uint4 kr[2];
-  uint32_t vw[8];
-  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr); load_tr(V, p.ldv, 0, p.Lk, vw); }
+  uint4 kr0, kr1, vr0, vr1;
+  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr0, kr1); load_rm(V, p.ldv, 0, p.Lk, vr0, vr1); }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * 64;
     __syncthreads();
-    store_rm(Ks, kr);
-    store_tr(Vt, vw);
+    store_rm(Ks, kr0, kr1);
+    store_rm(Vs, vr0, vr1);
     __syncthreads();
-    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr); load_tr(V, p.ldv, k0 + 64, p.Lk, vw); }
+    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr0, kr1); load_rm(V, p.ldv, k0 + 64, p.Lk, vr0, vr1); }
 
     f32x16 st[2];
 #pragma unroll
@@ -174,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) 
         const int sg = kt * 2 + s2;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const half8 a = *(const half8*)(Vt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          const half8 a = tr_frag8(Vs, 16 * sg, dt * 32, lane);
           ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, ot[dt], 0, 0, 0);
         }
       }
@@ -200,10 +186,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) 
 // =============================================================== backward: dQ (+ delta)
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc p) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * 8192];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* const Ks = smem;
-  char* const Kt = smem + 8192;
-  char* const Vs = smem + 16384;
+  char* const Vs = smem + 8192;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
   const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
@@ -240,15 +225,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
   if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);
   const int ntiles = (max(kend, 0) + 63) / 64;
 
-  uint4 kr[2], vr[2];
-  uint32_t kw[8];
-  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr); load_rm(V, p.ldv, 0, p.Lk, vr); load_tr(K, p.ldk, 0, p.Lk, kw); }
+  uint4 kr0, kr1, vr0, vr1;
+  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr0, kr1); load_rm(V, p.ldv, 0, p.Lk, vr0, vr1); }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * 64;
     __syncthreads();
-    store_rm(Ks, kr); store_rm(Vs, vr); store_tr(Kt, kw);
+    store_rm(Ks, kr0, kr1); store_rm(Vs, vr0, vr1);
     __syncthreads();
-    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr); load_rm(V, p.ldv, k0 + 64, p.Lk, vr); load_tr(K, p.ldk, k0 + 64, p.Lk, kw); }
+    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr0, kr1); load_rm(V, p.ldv, k0 + 64, p.Lk, vr0, vr1); }
 
     f32x16 st[2], dp[2];
 #pragma unroll
@@ -281,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
         const int sg = kt * 2 + s2;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const half8 a = *(const half8*)(Kt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          const half8 a = tr_frag8(Ks, 16 * sg, dt * 32, lane);
           dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, dsb, dqt[dt], 0, 0, 0);
         }
       }
@@ -304,12 +288,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 // One wave owns 32 keys (on the lanes); the block sweeps 64-query tiles.
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512];
   char* const Qs = smem;
-  char* const Qt = smem + 8192;
-  char* const dOs = smem + 16384;
-  char* const dOt = smem + 24576;
-  float* const lse_s = (float*)(smem + 32768);
+  char* const dOs = smem + 8192;
+  float* const lse_s = (float*)(smem + 16384);
   float* const del_s = lse_s + 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128;
@@ -339,19 +321,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
   if (CAUSAL) qstart = max(0, kb0 - coff) / 64 * 64;  // queries before the block's first key see none of its keys
   const int ntiles = (p.Lq - qstart + 63) / 64;
 
-  uint4 qr[2], dr[2];
-  uint32_t qw[8], dw[8];
+  uint4 qr0, qr1, dr0, dr1;
   float lse_r = 0.f, del_r = 0.f;
   auto load_all = [&](int q0) {
-    load_rm(Q, p.ldq, q0, p.Lq, qr); load_rm(dO, p.lddo, q0, p.Lq, dr);
-    load_tr(Q, p.ldq, q0, p.Lq, qw); load_tr(dO, p.lddo, q0, p.Lq, dw);
+    load_rm(Q, p.ldq, q0, p.Lq, qr0, qr1); load_rm(dO, p.lddo, q0, p.Lq, dr0, dr1);
     if (threadIdx.x < 64) { const int qq = min(q0 + (int)threadIdx.x, p.Lq - 1); lse_r = LSE[qq]; del_r = Delta[qq]; }
   };
   if (ntiles > 0) load_all(qstart);
   for (int t = 0; t < ntiles; ++t) {
     const int q0 = qstart + t * 64;
     __syncthreads();
-    store_rm(Qs, qr); store_rm(dOs, dr); store_tr(Qt, qw); store_tr(dOt, dw);
+    store_rm(Qs, qr0, qr1); store_rm(dOs, dr0, dr1);
     if (threadIdx.x < 64) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
     __syncthreads();
     if (t + 1 < ntiles) load_all(q0 + 64);
@@ -390,8 +370,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
         const int sg = qt * 2 + s2;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const half8 a1 = *(const half8*)(dOt + lds_off(dt * 32 + lr, 2 * sg + lh));
-          const half8 a2 = *(const half8*)(Qt + lds_off(dt * 32 + lr, 2 * sg + lh));
+          const half8 a1 = tr_frag8(dOs, 16 * sg, dt * 32, lane);
+          const half8 a2 = tr_frag8(Qs, 16 * sg, dt * 32, lane);
           dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb, dvt[dt], 0, 0, 0);
           dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, dsb, dkt[dt], 0, 0, 0);
         }
