@@ -414,6 +414,7 @@ void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
 
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
+int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -467,7 +468,10 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   } else if (skinny) {
     if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
-    ns_gemm_ring_launch(d, st);
+    // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the 256^2 ring
+    const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const bool big = g_use_ring == 3 || (g_use_ring == 1 && d->N >= 256 && tiles256 >= 192);
+    if (big) ns_gemm_ring256_launch(d, st); else ns_gemm_ring_launch(d, st);
   } else {
     if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);
   }

@@ -14,8 +14,9 @@ __device__ __forceinline__ long long ns_rm_off64(const ns_rowmap& m, int row) {
 
 template <int BM_, int BN_, int NTHREADS_>
 __device__ __forceinline__ void ns_nt_epilogue(const ns_gemm_desc& p, const float* ct, int m0, int n0, int tid) {
-  constexpr int TPR = BN_ == 128 ? 16 : 8;  // threads per tile row
-  constexpr int GPT = BN_ == 128 ? 2 : 1;   // 4-column groups per thread (second one 64 columns on)
+  constexpr int TPR = BN_ == 256 ? 32 : (BN_ == 128 ? 16 : 8);  // threads per tile row
+  constexpr int GPT = BN_ >= 128 ? 2 : 1;   // 4-column groups per thread (second one BN/2 columns on)
+  constexpr int GOFF = BN_ / 2;
   constexpr int RPP = NTHREADS_ / TPR;      // rows per pass
   const int cg = tid % TPR, r0 = tid / TPR;
   half_t* const C16 = (half_t*)p.C16;
@@ -29,7 +30,7 @@ __device__ __forceinline__ void ns_nt_epilogue(const ns_gemm_desc& p, const floa
   bool colok[GPT];
 #pragma unroll
   for (int g = 0; g < GPT; ++g) {
-    const int col = n0 + cg * 4 + g * 64;
+    const int col = n0 + cg * 4 + g * GOFF;
     colok[g] = col + 4 <= p.N;
     bias4[g] = (p.bias && colok[g]) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -44,7 +45,7 @@ __device__ __forceinline__ void ns_nt_epilogue(const ns_gemm_desc& p, const floa
 #pragma unroll
     for (int g = 0; g < GPT; ++g) {
       if (!colok[g]) continue;
-      const int cl = cg * 4 + g * 64, col = n0 + cl;
+      const int cl = cg * 4 + g * GOFF, col = n0 + cl;
       const float4 a = *(const float4*)(ct + rl * BN_ + cl);
       float v[4] = {a.x * alpha + bias4[g].x, a.y * alpha + bias4[g].y, a.z * alpha + bias4[g].z, a.w * alpha + bias4[g].w};
       if (p.C32) *(float4*)(p.C32 + (long long)row * p.ldc32 + col) = make_float4(v[0], v[1], v[2], v[3]);

@@ -30,6 +30,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// K tails: chunks beyond the valid K range are fetched from a block of zeros, so the MFMA loop is branch-free
+__device__ __attribute__((aligned(16))) const uint32_t ns_zero_chunk128[4] = {0, 0, 0, 0};
+
 template <bool DROP>
 __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,30 +102,29 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     char* const dst = smem + (s % NST) * STAGE_BYTES + (wave * 2) * 1024;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      // a chunk beyond the valid K range is redirected to chunk 0 (valid memory, never consumed)
-      const int ko = (my_chunk[jj] * 8 < klen) ? k0 : k0 - my_chunk[jj] * 8;
-      glds16((is2 ? a2_src[jj] : a_src[jj]) + ko, dst + jj * 1024);
-      glds16((is2 ? b2_src[jj] : b_src[jj]) + ko, dst + HALF_BYTES + jj * 1024);
+      const bool ok = my_chunk[jj] * 8 < klen;
+      glds16(ok ? (is2 ? a2_src[jj] : a_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + jj * 1024);
+      glds16(ok ? (is2 ? b2_src[jj] : b_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + HALF_BYTES + jj * 1024);
     }
   };
-  auto compute = [&](int buf, int klen) __attribute__((always_inline)) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* as = smem + buf * STAGE_BYTES;
     const char* bs = as + HALF_BYTES;
+    half8 af[2][2], bf[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      if (s * 16 < klen) {
-        half8 af[2], bf[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *(const half8*)(as + lds_off32(wm * 64 + i * 32 + lr, 2 * s + lh));
+      for (int i = 0; i < 2; ++i) af[s][i] = *(const half8*)(as + lds_off32(wm * 64 + i * 32 + lr, 2 * s + lh));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *(const half8*)(bs + lds_off32(wn * 64 + j * 32 + lr, 2 * s + lh));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < 2; ++j) bf[s][j] = *(const half8*)(bs + lds_off32(wn * 64 + j * 32 + lr, 2 * s + lh));
     }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
   };
 
   // ---- prologue: NST-1 slices in flight
@@ -139,8 +141,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     __builtin_amdgcn_s_barrier();   // every wave's slice-s DMA has landed; every wave finished slice s-1
     asm volatile("" ::: "memory");
     if (s + NST - 1 < nsteps) issue(s + NST - 1);   // refills the buffer slice s-1 lived in
-    bool is2; int k0, klen; step_info(s, is2, k0, klen);
-    compute(s % NST, klen);
+    compute(s % NST);
     if (DROP && seg2_first && s == steps2 - 1) {
       const float drop_inv = 1.f / (1.f - p.drop_p);
       const uint32_t drop_thr = (uint32_t)(p.drop_p * 4294967296.f);

@@ -61,7 +61,12 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
         L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
         return
     # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
-    kind = "tn" if flags & NS_GEMM_TN else ("nt32" if N <= 96 else "nt128")
+    if flags & NS_GEMM_TN:
+        kind = "tn"
+    elif N <= 96:
+        kind = "nt32"
+    else:   # mirrors the dispatch in csrc/ns_gemm.hip
+        kind = "nt256" if (N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")

@@ -18,3 +18,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _ring_mode_from_env():
+    """NS_RING=0/2/3 forces a GEMM kernel variant for the whole test session (default: auto dispatch)."""
+    mode = os.environ.get("NS_RING")
+    if mode is not None:
+        from neuspeech1_amd import lib
+        lib.load().ns_debug_set_ring(int(mode))
+    yield

@@ -13,10 +13,10 @@ from neuspeech1_amd.ops import rowmap  # noqa: E402
 dev = torch.device("cuda:0")
 F16, F32 = torch.float16, torch.float32
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-if os.environ.get("NS_RING", "1") == "0":
+if os.environ.get("NS_RING", "1") != "1":
     from neuspeech1_amd import lib as _l
-    _l.load().ns_debug_set_ring(0)
-    print("[ring kernel disabled]")
+    _l.load().ns_debug_set_ring(int(os.environ["NS_RING"]))
+    print(f"[ns_debug_set_ring({os.environ['NS_RING']})]")
 
 
 def rnd(*s, dtype=F16, scale=1.0):
