@@ -34,24 +34,46 @@ void ns_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- device math
+// exact-erf GELU (torch.nn.functional.gelu default) evaluated with the Abramowitz-Stegun 7.1.26 rational form of
+// erf (|error| <= 1.5e-7, far below the fp16 rounding of every value these feed): ~12 VALU + one exp + one rcp
+// instead of libm's branchy erff.  The same exp(-x^2/2) serves the pdf term of the derivative.
+__device__ __forceinline__ void ns_gelu_terms(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);                       // = exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;                // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143267794f * e;
+}
 __device__ __forceinline__ float ns_gelu(float x) {
-  // exact (erf) GELU, torch.nn.functional.gelu default
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float cdf, pdf;
+  ns_gelu_terms(x, cdf, pdf);
+  return x * cdf;
 }
 __device__ __forceinline__ float ns_gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  ns_gelu_terms(x, cdf, pdf);
   return cdf + x * pdf;
 }
 
-// counter-based dropout keep-decision: same (seed,row,col) -> same decision in
-// the forward LoRA-down kernel, the dgrad epilogue and the wgrad staging.
+// LoRA-dropout keep decision, identical in the forward down-projection (A operand), the dgrad epilogue mask and
+// the weight-gradient staging: one 32-bit hash per group of 4 consecutive columns, one byte per element, keep iff
+// byte >= thr8.  The drop probability is therefore quantised to thr8/256 (0.05 -> 13/256 = 0.0508) and the
+// survivors are scaled by 1/(1 - thr8/256).
 __device__ __forceinline__ uint32_t ns_hash3(uint32_t seed, uint32_t a, uint32_t b) {
   uint32_t x = seed ^ (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u);
   x ^= x >> 16; x *= 0x7FEB352Du;
   x ^= x >> 15; x *= 0x846CA68Bu;
   x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t ns_drop_thr8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
+__device__ __forceinline__ float ns_drop_inv(float p) { return 256.0f / (256.0f - (float)ns_drop_thr8(p)); }
+__device__ __forceinline__ uint32_t ns_drop_word(uint32_t seed, uint32_t row, uint32_t col4) { return ns_hash3(seed, row, col4); }
+__device__ __forceinline__ bool ns_keep(uint32_t word, uint32_t col, uint32_t thr8) { return ((word >> ((col & 3) * 8)) & 0xFFu) >= thr8; }
+__device__ __forceinline__ bool ns_keep_el(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr8) {
+  return ns_keep(ns_drop_word(seed, row, col >> 2), col, thr8);
 }
 
 __device__ __forceinline__ float ns_wave_sum(float v) {

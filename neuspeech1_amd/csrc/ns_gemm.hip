@@ -37,9 +37,6 @@ __device__ __forceinline__ long long rm_off64(const ns_rowmap& m, int row) {
 }
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ bool keep_el(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr) {
-  return ns_hash3(seed, row, col) >= thr;
-}
 
 template <bool TN, int BN, bool DROP>
 __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc p) {
@@ -75,8 +72,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float drop_inv = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 4294967296.f) : 0u;
+  const float drop_inv = DROP ? ns_drop_inv(p.drop_p) : 1.f;
+  const uint32_t drop_thr = DROP ? ns_drop_thr8(p.drop_p) : 0u;
 
   // ------------------------------------------------------------------ staging state
   const int st_chunk = tid & 7, st_row = tid >> 3;
@@ -155,11 +152,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
       for (int it = 0; it < 4; ++it) {
         const uint32_t grow = (uint32_t)(m0 + st_row + 32 * it);
         uint32_t w[4] = {st.a[it].x, st.a[it].y, st.a[it].z, st.a[it].w};
+        const uint32_t dw[2] = {ns_drop_word(p.drop_seed, grow, (uint32_t)ko >> 2), ns_drop_word(p.drop_seed, grow, ((uint32_t)ko >> 2) + 1)};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           half2v hv = __builtin_bit_cast(half2v, w[e]);
-          hv[0] = keep_el(p.drop_seed, grow, (uint32_t)(ko + 2 * e), drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
-          hv[1] = keep_el(p.drop_seed, grow, (uint32_t)(ko + 2 * e + 1), drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
+          hv[0] = ns_keep(dw[e >> 1], 2 * e, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
+          hv[1] = ns_keep(dw[e >> 1], 2 * e + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
           w[e] = __builtin_bit_cast(uint32_t, hv);
         }
         st.a[it] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -205,8 +203,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
           if (DROP && mask_b) {
             const uint32_t grow = (uint32_t)(kb + rl);
             half2v hv = __builtin_bit_cast(half2v, v);
-            hv[0] = keep_el(p.drop_seed, grow, (uint32_t)col, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
-            hv[1] = keep_el(p.drop_seed, grow, (uint32_t)col + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
+            const uint32_t dwd = ns_drop_word(p.drop_seed, grow, (uint32_t)col >> 2);
+            hv[0] = ns_keep(dwd, (uint32_t)col, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
+            hv[1] = ns_keep(dwd, (uint32_t)col + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
             v = __builtin_bit_cast(uint32_t, hv);
           }
         }
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
             for (int r = 0; r < 16; ++r) {
               const uint32_t row = (uint32_t)(m0 + wm * WAVE_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
               const uint32_t col = (uint32_t)(n0 + wn * WAVE_N + j * 32 + lr);
-              acc[i][j][r] = keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] * drop_inv : 0.f;
+              acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] * drop_inv : 0.f;
             }
       }
       if (more) { if constexpr (TN) store_tn(cur ^ 1, NS_ST8); else store_nt(cur ^ 1, NS_ST8); }

@@ -324,3 +324,51 @@ def test_adamw_clip_scaler(ops, dev):
         sched.step()
     assert step.item() == 5
     close(p, ref_p.detach(), 2e-6, 2e-5, "adamw")
+
+
+# --------------------------------------------------------------------------- LoRA dropout mask consistency
+def _keep_mask(seed, rows, cols, p, dev):
+    """numpy restatement of ns_keep_el (csrc/ns_common.h): one hash per (row, col>>2), one byte per element."""
+    import numpy as np
+    thr8 = int(p * 256.0 + 0.5)
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    c4 = (np.arange(cols, dtype=np.uint64) >> 2)[None, :]
+    M32 = np.uint64(0xFFFFFFFF)
+    x = (np.uint64(seed) ^ ((r * np.uint64(0x9E3779B1)) & M32) ^ ((c4 * np.uint64(0x85EBCA77)) & M32)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    byte = (x >> ((np.arange(cols, dtype=np.uint64) & np.uint64(3)) * np.uint64(8))[None, :]) & np.uint64(0xFF)
+    keep = torch.from_numpy((byte >= thr8).astype(np.float32)).to(dev)
+    return keep, 256.0 / (256.0 - thr8)
+
+
+def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
+    M, K, N, r, p, seed = 640, 512, 512, 32, 0.05, 1234567
+    x = rnd((M, K), dev, 1.0, seed=1)
+    A = rnd((r, K), dev, 0.05, seed=2)
+    keep, inv = _keep_mask(seed, M, K, p, dev)
+    assert abs(1.0 - keep.mean().item() - 13 / 256) < 5e-3
+    xd = (x.float() * keep * inv).half()       # what the kernels see after masking (rounded like they round)
+    # forward down-projection: u = drop(x) A^T
+    u = torch.empty(M, r, device=dev, dtype=torch.float16)
+    ops.gemm(A=x, am=ops.rowmap(K), K=K, B=A, ldb=K, M=M, N=r, C16=u, c16m=ops.rowmap(r), flags=ops.NS_GEMM_DROP_A,
+             drop_p=p, drop_seed=seed)
+    close(u, xd.float() @ A.float().T, 1e-2, 5e-3, "dropout down-projection")
+    # dgrad: dx = dy W + mask * (du A) / (1-p)   (all three GEMM kernels that carry the mask)
+    dy, W = rnd((M, N), dev, 0.5, seed=3), rnd((N, K), dev, 0.05, seed=4)
+    du, AT = rnd((M, r), dev, 0.5, seed=5), A.t().contiguous()
+    ref = dy.float() @ W.float() + keep * inv * (du.float() @ A.float())
+    from neuspeech1_amd import lib
+    for mode in (0, 2, 3):
+        lib.load().ns_debug_set_ring(mode)
+        dx = torch.empty(M, K, device=dev, dtype=torch.float16)
+        ops.gemm(A=dy, am=ops.rowmap(N), K=N, B=W.t().contiguous(), ldb=N, M=M, N=K, A2=du, am2=ops.rowmap(r), K2=r,
+                 B2=AT, ldb2=r, C16=dx, c16m=ops.rowmap(K), drop_p=p, drop_seed=seed)
+        close(dx, ref, 2e-2, 5e-3, f"dropout dgrad (ring mode {mode})")
+        # wgrad: dA = du^T drop(x)
+        dA = torch.zeros(r, K, device=dev)
+        ops.gemm(A=du, am=ops.rowmap(r), K=M, B=x, bm=ops.rowmap(K), M=r, N=K, C32=dA, ldc32=K,
+                 flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=3, drop_p=p, drop_seed=seed)
+        close(dA, du.float().T @ xd.float(), 3e-2, 3e-3, f"dropout wgrad (ring mode {mode})")
+    lib.load().ns_debug_set_ring(1)
