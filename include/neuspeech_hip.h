@@ -239,8 +239,11 @@ typedef struct {
 } ns_logits_proc_desc;
 int ns_logits_process(const ns_logits_proc_desc* d, void* stream);
 
-/* top-k (k <= 16) of each group of n contiguous floats, ordered (value desc, index asc) */
-int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* stream);
+/* top-k (k <= 16) of each group of n contiguous floats, ordered (value desc, index asc); two-stage (per-chunk
+ * candidates in `workspace`, then a merge) */
+size_t ns_topk_workspace_bytes(int groups, long long n, int k);
+int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* workspace,
+                   void* stream);
 
 /* HF beam-search bookkeeping for one step (HF:generation/utils.py:3077-3204, :3008-3075): from the top-2*beams
  * candidates pick the next running beams, merge just-finished hypotheses (score / (cur+1-prompt)^lp) into the

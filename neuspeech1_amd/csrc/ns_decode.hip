@@ -181,34 +181,74 @@ __global__ __launch_bounds__(256) void logits_process_kernel(const ns_logits_pro
   }
 }
 
-// top-k of n contiguous floats per group; order = (value desc, index asc); k <= 16
-__global__ __launch_bounds__(256) void topk_groups_kernel(const float* __restrict__ x, long long n, int k,
-                                                          float* __restrict__ vals, int* __restrict__ idx) {
+// top-k of n contiguous floats per group; order = (value desc, index asc); k <= 16.  Two stages: each of `nchunks`
+// blocks per group selects the top-k of its chunk out of LDS (k cheap passes), then one block per group merges the
+// nchunks*k candidates.  Identical result to k lexicographic passes over the whole group.
+constexpr int TOPK_CHUNK = 8192;
+
+__device__ __forceinline__ void blk_argmax_after(float& bv, int& bi, float* shv, int* shi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = bv; shi[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  bv = shv[0]; bi = shi[0];
+  for (int w = 1; w < 4; ++w)
+    if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+}
+
+__global__ __launch_bounds__(256) void topk_stage1_kernel(const float* __restrict__ x, long long n, int k, int nchunks,
+                                                          float* __restrict__ cv, int* __restrict__ ci) {
+  __shared__ float buf[TOPK_CHUNK];
   __shared__ float shv[4];
   __shared__ int shi[4];
-  const float* xr = x + (long long)blockIdx.x * n;
+  const int grp = blockIdx.y, ch = blockIdx.x;
+  const long long lo = (long long)ch * TOPK_CHUNK;
+  const int len = (int)min((long long)TOPK_CHUNK, n - lo);
+  const float* xr = x + (long long)grp * n + lo;
+  for (int i = threadIdx.x; i < len; i += 256) buf[i] = xr[i];
+  __syncthreads();
   float pv = INFINITY;
   int pi = -1;
   for (int t = 0; t < k; ++t) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (long long i = threadIdx.x; i < n; i += 256) {
-      const float v = xr[i];
-      const bool after = (v < pv) || (v == pv && (int)i > pi);
-      if (after && (v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; }
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const float v = buf[i];
+      const bool after = (v < pv) || (v == pv && i > pi);
+      if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    blk_argmax_after(bv, bi, shv, shi);
+    if (threadIdx.x == 0) {
+      cv[((long long)grp * nchunks + ch) * k + t] = bv;
+      ci[((long long)grp * nchunks + ch) * k + t] = bi == 0x7fffffff ? 0x7fffffff : (int)(lo + bi);
     }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = bv; shi[threadIdx.x >> 6] = bi; }
-    __syncthreads();
-    bv = shv[0]; bi = shi[0];
-    for (int w = 1; w < 4; ++w)
-      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+    pv = bv; pi = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_stage2_kernel(const float* __restrict__ cv, const int* __restrict__ ci, int ncand,
+                                                          int k, float* __restrict__ vals, int* __restrict__ idx) {
+  __shared__ float shv[4];
+  __shared__ int shi[4];
+  const float* v = cv + (long long)blockIdx.x * ncand;
+  const int* id = ci + (long long)blockIdx.x * ncand;
+  float pv = INFINITY;
+  int pi = -1;
+  for (int t = 0; t < k; ++t) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < ncand; i += 256) {
+      const float x = v[i];
+      const int gi = id[i];
+      const bool after = (x < pv) || (x == pv && gi > pi);
+      if (after && (x > bv || (x == bv && gi < bi))) { bv = x; bi = gi; }
+    }
+    blk_argmax_after(bv, bi, shv, shi);
     if (threadIdx.x == 0) { vals[blockIdx.x * k + t] = bv; idx[blockIdx.x * k + t] = bi; }
     pv = bv; pi = bi;
   }
@@ -380,9 +420,21 @@ extern "C" int ns_logits_process(const ns_logits_proc_desc* d, void* stream) {
   return NS_OK;
 }
 
-extern "C" int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* stream) {
-  NS_CHECK_ARG(x && vals && idx && groups > 0 && n > 0 && k > 0 && k <= 16 && n < 0x7fffffffLL, "ns_topk_groups: bad arguments");
-  hipLaunchKernelGGL(topk_groups_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, x, n, k, vals, idx);
+extern "C" size_t ns_topk_workspace_bytes(int groups, long long n, int k) {
+  const long long nchunks = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  return (size_t)groups * nchunks * k * (sizeof(float) + sizeof(int));
+}
+
+extern "C" int ns_topk_groups(const float* x, int groups, long long n, int k, float* vals, int* idx, void* workspace,
+                              void* stream) {
+  NS_CHECK_ARG(x && vals && idx && workspace && groups > 0 && n > 0 && k > 0 && k <= 16 && n < 0x7fffffffLL,
+               "ns_topk_groups: bad arguments");
+  const int nchunks = (int)((n + TOPK_CHUNK - 1) / TOPK_CHUNK);
+  float* cv = (float*)workspace;
+  int* ci = (int*)(cv + (size_t)groups * nchunks * k);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(topk_stage1_kernel, dim3(nchunks, groups), dim3(256), 0, st, x, n, k, nchunks, cv, ci);
+  hipLaunchKernelGGL(topk_stage2_kernel, dim3(groups), dim3(256), 0, st, cv, ci, nchunks * k, k, vals, idx);
   NS_CHECK_LAUNCH("ns_topk_groups");
   return NS_OK;
 }

@@ -452,7 +452,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   if (d->flags & NS_GEMM_DGELU) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU needs P16");
   NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "ns_gemm: drop_p out of range");
 
-  const bool skinny = !tn && d->N <= 96;
+  // skinny-N tiles (128x32) also serve small-M decode GEMMs: 4x more workgroups than 128x128 tiles when M <= 1024
+  const bool skinny = !tn && (d->N <= 96 || (d->M <= 1024 && d->N <= 4096));
   const bool drop = d->drop_p > 0.f;
   const int bn = skinny ? 32 : 128;
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
@@ -469,7 +470,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
     // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the 256^2 ring
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    const bool big = g_use_ring == 3 || (g_use_ring == 1 && d->N >= 256 && tiles256 >= 192);
+    const bool big = g_use_ring == 3 || (g_use_ring == 1 && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
     if (big) ns_gemm_ring256_launch(d, st); else ns_gemm_ring_launch(d, st);
   } else {
     if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);

@@ -134,7 +134,8 @@ SIGNATURES = {
     "ns_argmax_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "ns_attn_decode": (C.c_int, [C.POINTER(AttnDecodeDesc), _vp]),
     "ns_logits_process": (C.c_int, [C.POINTER(LogitsProcDesc), _vp]),
-    "ns_topk_groups": (C.c_int, [_vp, _i, C.c_longlong, _i, _vp, _vp, _vp]),
+    "ns_topk_workspace_bytes": (C.c_size_t, [_i, C.c_longlong, _i]),
+    "ns_topk_groups": (C.c_int, [_vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "ns_beam_update": (C.c_int, [C.POINTER(BeamDesc), _vp]),
     "ns_anc_update": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ns_greedy_update": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),

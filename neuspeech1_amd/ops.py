@@ -63,10 +63,10 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
     if flags & NS_GEMM_TN:
         kind = "tn"
-    elif N <= 96:
+    elif N <= 96 or (M <= 1024 and N <= 4096):
         kind = "nt32"
     else:   # mirrors the dispatch in csrc/ns_gemm.hip
-        kind = "nt256" if (N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
+        kind = "nt256" if (N >= 256 and M >= 2048 and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
@@ -184,8 +184,16 @@ def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, be
     L.check(L.load().ns_logits_process(C.byref(d), _stream()), "ns_logits_process")
 
 
+_topk_ws = {}
+
+
 def topk_groups(x32, groups, n, k, vals, idx):
-    L.check(L.load().ns_topk_groups(ptr(x32), groups, n, k, ptr(vals), ptr(idx), _stream()), "ns_topk_groups")
+    key = (x32.device, groups, n, k)
+    ws = _topk_ws.get(key)
+    if ws is None:
+        ws = torch.empty(L.load().ns_topk_workspace_bytes(groups, n, k), device=x32.device, dtype=torch.uint8)
+        _topk_ws[key] = ws
+    L.check(L.load().ns_topk_groups(ptr(x32), groups, n, k, ptr(vals), ptr(idx), ptr(ws), _stream()), "ns_topk_groups")
 
 
 def beam_update(**kw):

@@ -1,0 +1,33 @@
+"""Decode throughput at BASELINE configs[3]: whisper-base, 273-ch, B=128, beam 5 + repetition penalty 5.0 + no-repeat-2,
+64 new tokens with EOS suppressed (every row does identical work).  tokens/s = emitted tokens (prompt excluded) summed over
+the batch / wall time including the encoder pass."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neuspeech1_amd.engine import MegWhisperEngine  # noqa: E402
+from neuspeech1_amd.generate import Generator  # noqa: E402
+from neuspeech1_amd.weights import WhisperDims, make_state_dict, synth_batch  # noqa: E402
+
+B = int(os.environ.get("B", 128))
+NEW = int(os.environ.get("NEW", 64))
+dev = torch.device("cuda:0")
+dims = WhisperDims(ch=273)
+eng = MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev)
+gen = Generator(eng)
+x, labels = synth_batch(dims, B, 1234)
+x = torch.from_numpy(x).to(dev)
+prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
+for nb, kw in ((1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = gen.generate(x, prompt, num_beams=nb, max_new_tokens=NEW, suppress_tokens=[dims.eos_id], check_every=8, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    n = B * (out.shape[1] - 4)
+    print(f"beams={nb}: {n} tokens in {dt * 1e3:.1f} ms -> {n / dt:.0f} tokens/s ({dt / (out.shape[1] - 4) * 1e3:.2f} ms/step incl. encoder)", flush=True)
