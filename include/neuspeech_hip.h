@@ -158,8 +158,24 @@ typedef struct {
   const void* src; void* dst;
   int32_t rows, cols, ld_src, ld_dst;
   float scale; int32_t transpose;
+  const float* colscale;   /* optional: src[r][c] is additionally multiplied by colscale[c] (AdaLoRA's diag(E)) */
 } ns_cast_job;
 int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream);
+
+/* ------------------------------------------------------------------------
+ * AdaLoRA (the reference's default adapter, finetune.py:205-208; arithmetic in peft's AdaLoraLayer / AdaLoraModel):
+ *   y = W x + b + B((A x) * E) * alpha / (r + 1e-5),  loss += orth_reg_weight * mean_P || P P^T - I ||_F.
+ * The engine folds diag(E) and the scale into the fp16 B operand (ns_cast_job.colscale); these two entry points
+ * turn the folded gradient back into dB / dE and add the regulariser's value and gradient.
+ * ---------------------------------------------------------------------- */
+int ns_adalora_fold_grads(const float* dBf, const float* B, const float* E, float* dB, float* dE, int N, int r,
+                          float s, void* stream);
+typedef struct {
+  const float* P; float* G;       /* parameter and its gradient (same layout) */
+  int32_t r, len, ld, is_b;       /* lora_A: (r x len) rows; lora_B: (len x r) with is_b = 1; ld = row stride */
+} ns_orth_job;
+int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, const float* loss_scale_dev,
+                float* reg_out_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused attention, head_dim 64.  Row (b*L + i) of each token-major matrix,

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void cast_jobs_kernel(const ns_cast_job* __res
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < j.rows && c < j.cols) dst[(size_t)r * j.ld_dst + c] = (half_t)(j.scale * src[(size_t)r * j.ld_src + c]);
+        if (r < j.rows && c < j.cols)
+          dst[(size_t)r * j.ld_dst + c] = (half_t)(j.scale * (j.colscale ? j.colscale[c] : 1.f) * src[(size_t)r * j.ld_src + c]);
       }
     } else {
       __syncthreads();
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void cast_jobs_kernel(const ns_cast_job* __res
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;  // dst is (cols x rows)
-        if (r < j.rows && c < j.cols) dst[(size_t)c * j.ld_dst + r] = (half_t)(j.scale * tile[tx][ty + 8 * i]);
+        if (r < j.rows && c < j.cols) dst[(size_t)c * j.ld_dst + r] = (half_t)(j.scale * (j.colscale ? j.colscale[c] : 1.f) * tile[tx][ty + 8 * i]);
       }
     }
   }
@@ -137,6 +138,62 @@ __global__ __launch_bounds__(256) void colsum_kernel(const half_t* __restrict__ 
     }
     atomicAdd(out + c, s0 * alpha);
     atomicAdd(out + c + 1, s1 * alpha);
+  }
+}
+
+// ---- AdaLoRA (finetune.py:205-208, peft AdaLoraLayer): Delta W = B diag(E) A * alpha/(r+1e-5)
+// gradient fold: the weight-gradient GEMM produces dBf = dY^T u for the folded operand Bf = s * B * diag(E);
+//   dB[n][k] += s * E[k] * dBf[n][k],   dE[k] += s * sum_n dBf[n][k] * B[n][k]
+__global__ __launch_bounds__(256) void adalora_fold_kernel(const float* __restrict__ dBf, const float* __restrict__ Bm,
+                                                           const float* __restrict__ E, float* __restrict__ dB,
+                                                           float* __restrict__ dE, int N, int r, float s) {
+  __shared__ float acc[32];
+  if (threadIdx.x < 32) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int total = N * r;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i % r;
+    const float g = dBf[i];
+    dB[i] += s * E[k] * g;
+    atomicAdd(&acc[k], s * g * Bm[i]);
+  }
+  __syncthreads();
+  if (threadIdx.x < r) atomicAdd(dE + threadIdx.x, acc[threadIdx.x]);
+}
+
+// orthogonality regulariser of AdaLoRA: loss += w/num * ||P P^T - I||_F (lora_A, r x in) or ||P^T P - I||_F (lora_B,
+// out x r); adds loss_scale * w/num * 2 (cov - I) P / ||cov - I||_F to the gradient.  One block per matrix, r <= 16.
+__global__ __launch_bounds__(256) void orth_reg_kernel(const ns_orth_job* __restrict__ jobs, float weight_over_num,
+                                                       const float* __restrict__ loss_scale, float* __restrict__ reg_out) {
+  const ns_orth_job j = jobs[blockIdx.x];
+  __shared__ float cov[16][17];
+  __shared__ float nrm;
+  const int r = j.r, len = j.len;     // P is (r x len) for lora_A [is_b = 0], (len x r) for lora_B [is_b = 1]
+  const float* P = j.P;
+  auto at = [&](int k, int t) -> float { return j.is_b ? P[(size_t)t * j.ld + k] : P[(size_t)k * j.ld + t]; };
+  for (int pr = threadIdx.x; pr < r * r; pr += 256) {
+    const int a = pr / r, b = pr % r;
+    float s = 0.f;
+    for (int t = 0; t < len; ++t) s += at(a, t) * at(b, t);
+    cov[a][b] = s - (a == b ? 1.f : 0.f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int a = 0; a < r; ++a)
+      for (int b = 0; b < r; ++b) s += cov[a][b] * cov[a][b];
+    nrm = sqrtf(s);
+    atomicAdd(reg_out, weight_over_num * nrm);
+  }
+  __syncthreads();
+  if (nrm <= 0.f) return;
+  const float coef = (loss_scale ? *loss_scale : 1.f) * weight_over_num * 2.f / nrm;
+  for (int i = threadIdx.x; i < r * len; i += 256) {
+    const int k = j.is_b ? i % r : i / len, t = j.is_b ? i / r : i % len;
+    float s = 0.f;
+    for (int b = 0; b < r; ++b) s += cov[k][b] * at(b, t);
+    float* g = j.is_b ? j.G + (size_t)t * j.ld + k : j.G + (size_t)k * j.ld + t;
+    *g += coef * s;
   }
 }
 
@@ -190,5 +247,24 @@ extern "C" int ns_colsum(const void* a16, float* out32, int rows, int cols, int 
   hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const half_t*)a16,
                      out32, rows, cols, ld, alpha);
   NS_CHECK_LAUNCH("ns_colsum");
+  return NS_OK;
+}
+
+extern "C" int ns_adalora_fold_grads(const float* dBf, const float* B, const float* E, float* dB, float* dE, int N, int r,
+                                     float s, void* stream) {
+  NS_CHECK_ARG(dBf && B && E && dB && dE && N > 0 && r > 0 && r <= 32, "ns_adalora_fold_grads: bad arguments");
+  int nb = (N * r + 255) / 256;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(adalora_fold_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dBf, B, E, dB, dE, N, r, s);
+  NS_CHECK_LAUNCH("ns_adalora_fold_grads");
+  return NS_OK;
+}
+
+extern "C" int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, const float* loss_scale_dev,
+                           float* reg_out_dev, void* stream) {
+  NS_CHECK_ARG(jobs_dev && njobs > 0 && reg_out_dev, "ns_orth_reg: bad arguments");
+  hipLaunchKernelGGL(orth_reg_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, weight_over_num, loss_scale_dev,
+                     reg_out_dev);
+  NS_CHECK_LAUNCH("ns_orth_reg");
   return NS_OK;
 }

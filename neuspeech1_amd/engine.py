@@ -36,13 +36,21 @@ F16, F32 = torch.float16, torch.float32
 
 @dataclass
 class LoraSpec:
+    """LoRA (finetune.py:210-211) or, with adalora=True, AdaLoRA at its initial rank (finetune.py:206-208: the rank
+    allocator is never invoked by the reference's Trainer, so r stays init_r)."""
     r: int = 32
     alpha: float = 64.0
     dropout: float = 0.05
+    adalora: bool = False
+    orth_reg_weight: float = 0.5
 
     @property
     def scale(self) -> float:
-        return self.alpha / self.r
+        return self.alpha / (self.r + 1e-5) if self.adalora else self.alpha / self.r
+
+    @property
+    def r_pad(self) -> int:
+        return (self.r + 15) // 16 * 16
 
 
 @dataclass
@@ -94,8 +102,9 @@ class MegWhisperEngine:
         g = lambda k: torch.as_tensor(sd[k]).to(self.dev, F32)  # noqa: E731
         self._sd_get = g
         s = 64 ** -0.5
-        self.r = lora.r if lora else 0
-        assert self.r % 16 == 0
+        self.r = lora.r_pad if lora else 0          # MFMA K granularity: ranks are zero-padded to a multiple of 16
+        self.r_real = lora.r if lora else 0
+        self.adalora = bool(lora and lora.adalora)
         # ---------------- frozen operand packs
         e = "model.encoder."
         self.enc_pos = g(e + "embed_positions.weight").contiguous()
@@ -162,6 +171,9 @@ class MegWhisperEngine:
                 segs += [(p + "self_attn.out_proj.lora_A", r * d), (p + "self_attn.out_proj.lora_B", d * r),
                          (p + "fc1.lora_A", r * d), (p + "fc1.lora_B", f * r),
                          (p + "fc2.lora_A", r * f), (p + "fc2.lora_B", d * r)]
+                if self.adalora:
+                    segs += [(p + "self_attn.qkv.lora_E", 3 * r), (p + "self_attn.out_proj.lora_E", r),
+                             (p + "fc1.lora_E", r), (p + "fc2.lora_E", r)]
         segs += [("model.encoder.conv2.wp", d * 3 * d), ("model.encoder.conv2.bias", d),
                  ("model.encoder.conv1.2.wp", d * 3 * d), ("model.encoder.conv1.2.bias", d),
                  ("model.encoder.conv1.0.wp", d * 3 * Cp), ("model.encoder.conv1.0.bias", d)]
@@ -182,23 +194,31 @@ class MegWhisperEngine:
             wp[:, :, :cin] = w.permute(0, 2, 1)
             self.pview(f"model.encoder.{nm}.bias").copy_(g(f"model.encoder.{nm}.bias"))
         if self.lora:
+            rr = self.r_real
+
+            def init_pair(a_view, b_view, e_view, key):
+                """a_view (r_pad, in), b_view (out, r_pad), e_view (r_pad,) or None; only the first rr ranks are live."""
+                if lora_sd is not None:
+                    a_view[:rr].copy_(torch.as_tensor(lora_sd[key + ".lora_A.weight"]))
+                    b_view[:, :rr].copy_(torch.as_tensor(lora_sd[key + ".lora_B.weight"]))
+                    if e_view is not None:
+                        e_view[:rr].copy_(torch.as_tensor(lora_sd[key + ".lora_E.weight"]).reshape(-1))
+                elif self.adalora:      # peft AdaLoraLayer.reset_lora_parameters: A, B ~ N(0, 0.02), E = 0
+                    a_view[:rr].normal_(0.0, 0.02)
+                    b_view[:, :rr].normal_(0.0, 0.02)
+                else:                   # peft LoRA: A kaiming_uniform(a=sqrt(5)), B = 0
+                    torch.nn.init.kaiming_uniform_(a_view[:rr], a=math.sqrt(5))
+
             for i in range(dims.enc_layers):
                 p = f"model.encoder.layers.{i}."
                 A = self.pview(p + "self_attn.qkv.lora_A").view(3, r, d)
+                E3 = self.pview(p + "self_attn.qkv.lora_E").view(3, r) if self.adalora else None
                 for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
-                    if lora_sd is not None:
-                        A[j].copy_(torch.as_tensor(lora_sd[p + f"self_attn.{nm}.lora_A.weight"]))
-                        self.pview(p + f"self_attn.{nm}.lora_B").view(d, r).copy_(
-                            torch.as_tensor(lora_sd[p + f"self_attn.{nm}.lora_B.weight"]))
-                    else:
-                        torch.nn.init.kaiming_uniform_(A[j], a=math.sqrt(5))
+                    init_pair(A[j], self.pview(p + f"self_attn.{nm}.lora_B").view(d, r), E3[j] if self.adalora else None,
+                              p + f"self_attn.{nm}")
                 for nm, (no, ki) in (("self_attn.out_proj", (d, d)), ("fc1", (f, d)), ("fc2", (d, f))):
-                    a = self.pview(p + nm + ".lora_A").view(r, ki)
-                    if lora_sd is not None:
-                        a.copy_(torch.as_tensor(lora_sd[p + nm + ".lora_A.weight"]))
-                        self.pview(p + nm + ".lora_B").view(no, r).copy_(torch.as_tensor(lora_sd[p + nm + ".lora_B.weight"]))
-                    else:
-                        torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+                    init_pair(self.pview(p + nm + ".lora_A").view(r, ki), self.pview(p + nm + ".lora_B").view(no, r),
+                              self.pview(p + nm + ".lora_E") if self.adalora else None, p + nm)
         self._build_operand_copies()
 
     def pview(self, name):
@@ -241,8 +261,9 @@ class MegWhisperEngine:
                 jobs.append((pp(p + "self_attn.qkv.lora_A"), o["AqkvT"].data_ptr(), 3 * r, d, d, 3 * r, 1.0, 1))
                 for j, (nm, s_) in enumerate((("q_proj", sc * qs), ("k_proj", sc), ("v_proj", sc))):
                     src = pp(p + f"self_attn.{nm}.lora_B")
-                    jobs.append((src, o["sBqkv"].data_ptr() + 2 * j * d * r, d, r, r, r, s_, 0))
-                    jobs.append((src, o[("sBqT", "sBkT", "sBvT")[j]].data_ptr(), d, r, r, d, s_, 1))
+                    ecol = pp(p + "self_attn.qkv.lora_E") + 4 * j * r if self.adalora else 0   # diag(E) folded into B
+                    jobs.append((src, o["sBqkv"].data_ptr() + 2 * j * d * r, d, r, r, r, s_, 0, ecol))
+                    jobs.append((src, o[("sBqT", "sBkT", "sBvT")[j]].data_ptr(), d, r, r, d, s_, 1, ecol))
                 for nm, key, no, ki in (("self_attn.out_proj", "out", d, d), ("fc1", "fc1", f, d), ("fc2", "fc2", d, f)):
                     o[key + "_A"] = z(r, ki)
                     o[key + "_AT"] = z(ki, r)
@@ -250,10 +271,27 @@ class MegWhisperEngine:
                     o[key + "_sBT"] = z(r, no)
                     jobs.append((pp(p + nm + ".lora_A"), o[key + "_A"].data_ptr(), r, ki, ki, ki, 1.0, 0))
                     jobs.append((pp(p + nm + ".lora_A"), o[key + "_AT"].data_ptr(), r, ki, ki, r, 1.0, 1))
-                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sB"].data_ptr(), no, r, r, r, sc, 0))
-                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sBT"].data_ptr(), no, r, r, no, sc, 1))
+                    ecol = pp(p + nm + ".lora_E") if self.adalora else 0
+                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sB"].data_ptr(), no, r, r, r, sc, 0, ecol))
+                    jobs.append((pp(p + nm + ".lora_B"), o[key + "_sBT"].data_ptr(), no, r, r, no, sc, 1, ecol))
                 self.lora_ops.append(o)
         self._job_table, self._njobs = ops.make_cast_jobs(jobs, self.dev)
+        self._orth_table = None
+        if self.adalora:
+            # orthogonality regulariser over every lora_A (r x in) and lora_B (out x r), live ranks only
+            oj, rr = [], self.r_real
+            gp = lambda name: self.G.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
+            for i in range(dims.enc_layers):
+                p = f"model.encoder.layers.{i}."
+                for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                    oj.append((pp(p + "self_attn.qkv.lora_A") + 4 * j * r * d, gp(p + "self_attn.qkv.lora_A") + 4 * j * r * d, rr, d, d, 0))
+                    oj.append((pp(p + f"self_attn.{nm}.lora_B"), gp(p + f"self_attn.{nm}.lora_B"), rr, d, r, 1))
+                for nm, no, ki in (("self_attn.out_proj", d, d), ("fc1", f, d), ("fc2", d, f)):
+                    oj.append((pp(p + nm + ".lora_A"), gp(p + nm + ".lora_A"), rr, ki, ki, 0))
+                    oj.append((pp(p + nm + ".lora_B"), gp(p + nm + ".lora_B"), rr, no, r, 1))
+            self._orth_table, self._n_orth = ops.make_orth_jobs(oj, self.dev)
+            self.reg_dev = torch.zeros(1, device=self.dev)
+            self._gbf = torch.zeros(max(d, f) * r, device=self.dev, dtype=F32)
         self.refresh_operands()
 
     def refresh_operands(self):
@@ -531,6 +569,13 @@ class MegWhisperEngine:
                               logits if compute_grad else None, self.nvalid_dev,
                               self.loss_scale_dev if compute_grad else None, self.loss_dev)
             loss = self.loss_dev
+            if self.adalora and compute_grad:
+                # AdaLoRA's orthogonality regulariser (value into reg_dev, gradient into G, which the caller zeroed)
+                self.reg_dev.zero_()
+                ops.orth_reg(self._orth_table, self._n_orth, self.lora.orth_reg_weight / self._n_orth,
+                             self.loss_scale_dev, self.reg_dev)
+                self.total_loss_dev = self.loss_dev + self.reg_dev
+                loss = self.total_loss_dev
         return loss, logits.view(B, L, dims.vocab_pad)[:, :, :dims.vocab]
 
     # ------------------------------------------------------------------ backward
@@ -592,14 +637,14 @@ class MegWhisperEngine:
                 # fc2: du = dy*sB ; dB = s*dy^T u ; dA = du^T gf_d ; dgf = dy*W + mask(du*A)
                 ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["fc2_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
                 self._cur_seed_save = self._cur_seed
-                self._wgrad(dy, d, b["u2"][i], r, M, d, r, p + "fc2.lora_B", alpha=sc)
+                self._wgrad_b(dy, d, b["u2"][i], r, M, d, p + "fc2", sc)
                 self._with_seed(seed + 3, lambda: self._wgrad(b["du"], r, b["gf"][i], f, M, r, f, p + "fc2.lora_A", drop=True))
                 self._with_seed(seed + 3, lambda: self._dgrad(dy, M, Lw["fc2"], b["dpre_f"], P16=b["pre_f"][i], A2=b["du"],
                                                                lda2=r, K2=r, B2=lo["fc2_AT"], drop=True))
                 # fc1
                 dpf = b["dpre_f"]
                 ops.gemm(A=dpf, am=rowmap(f), K=f, B=lo["fc1_sBT"], ldb=f, M=M, N=r, C16=b["du"], c16m=rowmap(r))
-                self._wgrad(dpf, f, b["u1"][i], r, M, f, r, p + "fc1.lora_B", alpha=sc)
+                self._wgrad_b(dpf, f, b["u1"][i], r, M, f, p + "fc1", sc)
                 self._with_seed(seed + 2, lambda: self._wgrad(b["du"], r, b["x2"][i], d, M, r, d, p + "fc1.lora_A", drop=True))
                 self._with_seed(seed + 2, lambda: self._dgrad(dpf, M, Lw["fc1"], b["dx16"], A2=b["du"], lda2=r, K2=r,
                                                                B2=lo["fc1_AT"], drop=True))
@@ -610,7 +655,7 @@ class MegWhisperEngine:
             dy = b["dh16"]
             if r:
                 ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["out_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
-                self._wgrad(dy, d, b["uo"][i], r, M, d, r, p + "self_attn.out_proj.lora_B", alpha=sc)
+                self._wgrad_b(dy, d, b["uo"][i], r, M, d, p + "self_attn.out_proj", sc)
                 self._with_seed(seed + 1, lambda: self._wgrad(b["du"], r, b["ao"][i], d, M, r, d,
                                                                p + "self_attn.out_proj.lora_A", drop=True))
                 self._with_seed(seed + 1, lambda: self._dgrad(dy, M, Lw["out"], b["dao"], A2=b["du"], lda2=r, K2=r,
@@ -625,9 +670,8 @@ class MegWhisperEngine:
                 for j, (nm, key, a) in enumerate((("q_proj", "sBqT", sc * qs), ("k_proj", "sBkT", sc), ("v_proj", "sBvT", sc))):
                     ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=d, B=lo[key], ldb=d, M=M, N=r, C16=(b["du3"], j * r),
                              c16m=rowmap(3 * r))
-                    ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=M, B=(b["uqkv"][i], j * r), bm=rowmap(3 * r), M=d, N=r,
-                             C32=self.G.data_ptr() + 4 * self.seg_off[p + f"self_attn.{nm}.lora_B"][0], ldc32=r,
-                             flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(M // 256, 192)), alpha=a)
+                    self._wgrad_b((dqkv, j * d), 3 * d, (b["uqkv"][i], j * r), 3 * r, M, d, p + f"self_attn.{nm}", a,
+                                  ename=p + "self_attn.qkv.lora_E", eoff=j * r)
                 self._with_seed(seed, lambda: self._wgrad(b["du3"], 3 * r, b["x1"][i], d, M, 3 * r, d,
                                                            p + "self_attn.qkv.lora_A", drop=True))
                 self._with_seed(seed, lambda: self._dgrad(dqkv, M, Lw["qkv"], b["dx16"], A2=b["du3"], lda2=3 * r, K2=3 * r,
@@ -645,6 +689,21 @@ class MegWhisperEngine:
             self._stem_backward(b)
         if on_ready is not None:
             on_ready(self.lora_end, self.n_train)
+
+    def _wgrad_b(self, dy16, ldy, u16, ldu, Mred, N, key, s, ename=None, eoff=0):
+        """LoRA-B weight gradient dB = s * dY^T u.  AdaLoRA: the GEMM yields the gradient of the folded operand
+        s*B*diag(E); ns_adalora_fold_grads turns it into dB and dE."""
+        r = self.r
+        if not self.adalora:
+            self._wgrad(dy16, ldy, u16, ldu, Mred, N, r, key + ".lora_B", alpha=s)
+            return
+        tmp = self._gbf[:N * r]
+        tmp.zero_()
+        ops.gemm(A=dy16, am=rowmap(ldy), K=Mred, B=u16, bm=rowmap(ldu), M=N, N=r, C32=tmp, ldc32=r,
+                 flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(Mred // 256, 192)))
+        en = ename or key + ".lora_E"
+        ops.adalora_fold_grads(tmp, self.pview(key + ".lora_B"), (self.pview(en), eoff), self.gview(key + ".lora_B"),
+                               (self.gview(en), eoff), N, r, s)
 
     def _with_seed(self, seed, fn):
         save = self._cur_seed

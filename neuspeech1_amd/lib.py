@@ -48,7 +48,13 @@ class CastJob(C.Structure):
         ("src", C.c_void_p), ("dst", C.c_void_p),
         ("rows", C.c_int32), ("cols", C.c_int32), ("ld_src", C.c_int32), ("ld_dst", C.c_int32),
         ("scale", C.c_float), ("transpose", C.c_int32),
+        ("colscale", C.c_void_p),
     ]
+
+
+class OrthJob(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("G", C.c_void_p), ("r", C.c_int32), ("len", C.c_int32), ("ld", C.c_int32),
+                ("is_b", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -128,6 +134,8 @@ SIGNATURES = {
     "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _vp]),
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
+    "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
     "ns_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

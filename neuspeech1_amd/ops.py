@@ -149,8 +149,9 @@ def adamw_step(p, g, m, v, n, cfg: AdamWCfg, step_dev, norm2_dev, found_inf_dev,
 def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
     """jobs: list of (src_ptr, dst_ptr, rows, cols, ld_src, ld_dst, scale, transpose) -> device table."""
     arr = (CastJob * len(jobs))()
-    for i, (s, dptr, r, c, lds, ldd, sc, tr) in enumerate(jobs):
-        arr[i] = CastJob(s, dptr, r, c, lds, ldd, sc, int(tr))
+    for i, job in enumerate(jobs):
+        s, dptr, r, c, lds, ldd, sc, tr = job[:8]
+        arr[i] = CastJob(s, dptr, r, c, lds, ldd, sc, int(tr), job[8] if len(job) > 8 else 0)
     raw = bytes(arr)
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return t, len(jobs)
@@ -210,3 +211,22 @@ def anc_update(anc_in, anc_out, parent, rows, ld, cur):
 def greedy_update(scores, rows, V, seqs, ld, cur, eos, pad, done, any_open, next_tok):
     L.check(L.load().ns_greedy_update(ptr(scores), rows, V, ptr(seqs), ld, cur, 0, eos, pad, ptr(done), ptr(any_open),
                                       ptr(next_tok), _stream()), "ns_greedy_update")
+
+
+# ----------------------------------------------------------------------------- AdaLoRA
+def adalora_fold_grads(dBf, B, E, dB, dE, N, r, s):
+    L.check(L.load().ns_adalora_fold_grads(ptr(dBf), ptr(B), ptr(E), ptr(dB), ptr(dE), N, r, s, _stream()),
+            "ns_adalora_fold_grads")
+
+
+def make_orth_jobs(jobs, device):
+    """jobs: list of (P_ptr, G_ptr, r, len, ld, is_b)"""
+    arr = (L.OrthJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i] = L.OrthJob(*j)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(jobs)
+
+
+def orth_reg(table, njobs, weight_over_num, loss_scale_dev, reg_out_dev):
+    L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), _stream()),
+            "ns_orth_reg")

@@ -33,10 +33,23 @@ class LoraConfig:
     peft_type: str = "LORA"
 
 
-class AdaLoraConfig:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("AdaLoRA (finetune.py --use_adalora=True) is not on the MI355X hot path yet: "
-                                  "pass --use_adalora=False (LoRA r=32, alpha=64, dropout 0.05)")
+@dataclass
+class AdaLoraConfig(LoraConfig):
+    """finetune.py:206-208.  The reference trains with the stock Seq2SeqTrainer and never calls
+    `update_and_allocate`, so the rank budget (target_r, tinit, tfinal, deltaT, beta1/2) is never applied: every
+    module stays at init_r and AdaLoRA reduces to the SVD-form adapter  y += B((A x) * E) * alpha / (init_r + 1e-5)
+    plus the orthogonality penalty  orth_reg_weight * mean(||A A^T - I||_F, ||B^T B - I||_F)  added to the loss
+    (peft AdaLoraModel.forward).  The allocator fields are carried for config round-trips only."""
+    init_r: int = 12
+    target_r: int = 8
+    beta1: float = 0.85
+    beta2: float = 0.85
+    tinit: int = 0
+    tfinal: int = 0
+    deltaT: int = 1
+    orth_reg_weight: float = 0.5
+    total_step: int | None = None
+    peft_type: str = "ADALORA"
 
 
 def prepare_model_for_kbit_training(model):
@@ -75,17 +88,24 @@ class PeftModel(nn.Module):
         if set(config.target_modules) != want:
             raise NotImplementedError("the HIP engine carries LoRA on ALL encoder q/k/v/out/fc1/fc2 modules "
                                       f"({len(want)} names); got {len(config.target_modules)} target modules")
-        if config.r % 16:
+        ada = isinstance(config, AdaLoraConfig)
+        if not ada and config.r % 16:
             raise NotImplementedError("LoRA rank must be a multiple of 16 (MFMA K granularity)")
         dev = model.device
         for name in config.target_modules:
             lin = model.get_submodule(name)
-            a = nn.Linear(lin.in_features, config.r, bias=False, device=dev)
-            b = nn.Linear(config.r, lin.out_features, bias=False, device=dev)
-            nn.init.kaiming_uniform_(a.weight, a=math.sqrt(5))
-            nn.init.zeros_(b.weight)
-            lin.lora_A = nn.ModuleDict({"default": a})
-            lin.lora_B = nn.ModuleDict({"default": b})
+            if ada:   # peft SVDLinear: parameters (not Linears); A, B ~ N(0, 0.02), E = 0
+                r = config.init_r
+                lin.lora_A = nn.ParameterDict({"default": nn.Parameter(torch.randn(r, lin.in_features, device=dev) * 0.02)})
+                lin.lora_E = nn.ParameterDict({"default": nn.Parameter(torch.zeros(r, 1, device=dev))})
+                lin.lora_B = nn.ParameterDict({"default": nn.Parameter(torch.randn(lin.out_features, r, device=dev) * 0.02)})
+            else:
+                a = nn.Linear(lin.in_features, config.r, bias=False, device=dev)
+                b = nn.Linear(config.r, lin.out_features, bias=False, device=dev)
+                nn.init.kaiming_uniform_(a.weight, a=math.sqrt(5))
+                nn.init.zeros_(b.weight)
+                lin.lora_A = nn.ModuleDict({"default": a})
+                lin.lora_B = nn.ModuleDict({"default": b})
             lin.weight.requires_grad = False
             if lin.bias is not None:
                 lin.bias.requires_grad = False
@@ -99,15 +119,27 @@ class PeftModel(nn.Module):
     def from_pretrained(cls, model, path, is_trainable=False, local_files_only=True, **_):
         with open(os.path.join(path, "adapter_config.json")) as f:
             raw = json.load(f)
-        cfg = LoraConfig(r=raw["r"], lora_alpha=raw["lora_alpha"], target_modules=raw["target_modules"],
-                         lora_dropout=raw.get("lora_dropout", 0.0), bias=raw.get("bias", "none"),
-                         modules_to_save=raw.get("modules_to_save") or [])
+        common = dict(lora_alpha=raw["lora_alpha"], target_modules=raw["target_modules"],
+                      lora_dropout=raw.get("lora_dropout", 0.0), bias=raw.get("bias", "none"),
+                      modules_to_save=raw.get("modules_to_save") or [])
+        if raw.get("peft_type") == "ADALORA":
+            cfg = AdaLoraConfig(r=raw.get("r", 8), **common,
+                                **{k: raw[k] for k in ("init_r", "target_r", "beta1", "beta2", "tinit", "tfinal", "deltaT",
+                                                       "orth_reg_weight", "total_step") if k in raw})
+        else:
+            cfg = LoraConfig(r=raw["r"], **common)
         pm = cls(model, cfg)
         from safetensors.torch import load_file
         sd = load_file(os.path.join(path, "adapter_model.safetensors"))
         own = dict(pm.named_parameters())
         for k, v in sd.items():
-            kk = k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+            if k.endswith(".ranknum"):
+                continue
+            kk = k
+            for t in ("lora_A", "lora_B", "lora_E"):
+                kk = kk.replace(f".{t}.weight", f".{t}.default.weight")
+                if kk.endswith("." + t):
+                    kk += ".default"
             own[kk].data.copy_(v.to(own[kk].device))
         if not is_trainable:
             for p in pm.parameters():
@@ -157,15 +189,20 @@ class PeftModel(nn.Module):
         print(f"trainable params: {tr:,d} || all params: {al:,d} || trainable%: {100 * tr / al:.4f}")
 
     def merge_and_unload(self):
-        """W <- W + (alpha/r) B A on every adapted Linear, adapters removed; returns the bare model."""
+        """W <- W + (alpha/r) B A  (AdaLoRA: alpha/(r+1e-5) B (A*E)) on every adapted Linear, adapters removed."""
         model = self.model
         cfg = self.peft_config["default"]
-        scale = cfg.lora_alpha / cfg.r
+        ada = isinstance(cfg, AdaLoraConfig)
+        scale = cfg.lora_alpha / (cfg.init_r + 1e-5) if ada else cfg.lora_alpha / cfg.r
         with torch.no_grad():
             for name in cfg.target_modules:
                 lin = model.get_submodule(name)
-                lin.weight.add_(scale * lin.lora_B["default"].weight.float() @ lin.lora_A["default"].weight.float())
-                del lin.lora_A, lin.lora_B
+                if ada:
+                    lin.weight.add_(scale * lin.lora_B["default"].float() @ (lin.lora_A["default"].float() * lin.lora_E["default"].float()))
+                    del lin.lora_A, lin.lora_B, lin.lora_E
+                else:
+                    lin.weight.add_(scale * lin.lora_B["default"].weight.float() @ lin.lora_A["default"].weight.float())
+                    del lin.lora_A, lin.lora_B
         model._peft = None
         model._engine = None
         return model

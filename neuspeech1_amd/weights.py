@@ -118,7 +118,7 @@ def make_state_dict(dims: WhisperDims, seed: int = 42) -> dict[str, np.ndarray]:
 LORA_SUFFIXES = ("k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2")
 
 
-def make_lora_state(dims: WhisperDims, r: int, seed: int = 7, b_std: float = 0.02) -> dict[str, np.ndarray]:
+def make_lora_state(dims: WhisperDims, r: int, seed: int = 7, b_std: float = 0.02, adalora: bool = False) -> dict[str, np.ndarray]:
     """LoRA A/B for every encoder q/k/v/out/fc1/fc2 (finetune.py:189-198).  PEFT initialises B to zero; tests use
     a non-zero B (b_std) so the side path and its gradients are exercised."""
     d, f = dims.d, dims.ffn
@@ -133,6 +133,8 @@ def make_lora_state(dims: WhisperDims, r: int, seed: int = 7, b_std: float = 0.0
             out_f = f if suf == "fc1" else d
             out[name + ".lora_A.weight"] = _gen(name + ".lora_A", (r, in_f), in_f ** -0.5, seed)
             out[name + ".lora_B.weight"] = _gen(name + ".lora_B", (out_f, r), b_std, seed)
+            if adalora:   # peft initialises E to zero; tests use a non-zero E so that every gradient path is live
+                out[name + ".lora_E.weight"] = _gen(name + ".lora_E", (r, 1), 0.5, seed)
     return out
 
 

@@ -52,8 +52,23 @@ def _lora_lin(x, sd, lora, name, scale):
     """y = W x + b (+ scale * B(A x))   peft lora.Linear.forward at dropout 0 (finetune.py:210-212)."""
     y = F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
     if lora is not None and (name + ".lora_A.weight") in lora:
-        y = y + scale * F.linear(F.linear(x, lora[name + ".lora_A.weight"]), lora[name + ".lora_B.weight"])
+        u = F.linear(x, lora[name + ".lora_A.weight"])
+        if (name + ".lora_E.weight") in lora:      # AdaLoRA (peft SVDLinear): B((A x) * E) * alpha / (r + 1e-5)
+            u = u * lora[name + ".lora_E.weight"].reshape(-1)
+        y = y + scale * F.linear(u, lora[name + ".lora_B.weight"])
     return y
+
+
+def adalora_orth_reg(lora):
+    """peft AdaLoraModel.forward: mean over every lora_A / lora_B of || P P^T - I ||_F (A) resp. || P^T P - I ||_F (B);
+    the caller multiplies by orth_reg_weight (finetune.py:207: 0.5)."""
+    tot, num = 0.0, 0
+    for k, p in lora.items():
+        if k.endswith("lora_A.weight") or k.endswith("lora_B.weight"):
+            cov = p @ p.T if "lora_A" in k else p.T @ p
+            tot = tot + torch.norm(cov - torch.eye(cov.shape[0]), p="fro")
+            num += 1
+    return tot / num
 
 
 def attention(sd, lora, prefix, x, kv, heads, mask, scale):
@@ -153,12 +168,14 @@ TRAINABLE_CONV = ("model.encoder.conv1.0.weight", "model.encoder.conv1.0.bias", 
                   "model.encoder.conv1.2.bias", "model.encoder.conv2.weight", "model.encoder.conv2.bias")
 
 
-def loss_and_grads(sd_np, lora_np, x_np, labels_np, dims, scale):
+def loss_and_grads(sd_np, lora_np, x_np, labels_np, dims, scale, orth_reg_weight=0.0):
     """Loss + gradients of the reference's trainable set: LoRA A/B on the encoder's q/k/v/out/fc1/fc2 and the
     three conv modules (finetune.py:187-212: target_modules + modules_to_save)."""
     sd = to_torch(sd_np, requires_grad=TRAINABLE_CONV)
-    lora = to_torch(lora_np, requires_grad=("lora_A.weight", "lora_B.weight")) if lora_np else None
+    lora = to_torch(lora_np, requires_grad=("lora_A.weight", "lora_B.weight", "lora_E.weight")) if lora_np else None
     loss, logits, enc = forward(sd, T(x_np), dims, labels=T(labels_np), lora=lora, scale=scale)
+    if orth_reg_weight and lora:
+        loss = loss + orth_reg_weight * adalora_orth_reg(lora)
     loss.backward()
     grads = {k: sd[k].grad for k in TRAINABLE_CONV}
     if lora:

@@ -10,7 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_finetune_then_evaluation_end_to_end(dev, tmp_path):
+@pytest.mark.parametrize("adalora", [False, True])
+def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
     import evaluation
     import finetune
     from neuspeech1_amd.synthetic import write_synthetic_dataset
@@ -19,7 +20,7 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path):
     common = ["--modal=eeg", "--eeg_ch=20", "--sampling_rate=200", "--timestamps=False", "--max_audio_len=2.0",
               "--language=Dutch", "--num_workers=0"]
     finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}",
-                   "--orig_sample_rate=200", "--use_adalora=False", "--fp16=True", "--num_train_epochs=2",
+                   "--orig_sample_rate=200", f"--use_adalora={adalora}", "--fp16=True", "--num_train_epochs=2",
                    "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
                    "--eval_steps=2", "--save_steps=2", "--warmup_steps=2", "--learning_rate=1e-3",
                    "--augment_config_path=None", "--max_steps=6"] + common)
@@ -29,9 +30,15 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path):
     assert len(logs) == 6 and logs[-1]["loss"] < logs[0]["loss"], logs
     from safetensors.torch import load_file
     sd = load_file(os.path.join(ck, "adapter_model.safetensors"))
-    assert "base_model.model.model.encoder.layers.0.self_attn.q_proj.lora_A.weight" in sd
+    if adalora:   # peft's AdaLoRA layout: bare parameters, rank 12, E moved off its zero init
+        assert sd["base_model.model.model.encoder.layers.0.self_attn.q_proj.lora_A"].shape == (12, 256)
+        assert sd["base_model.model.model.encoder.layers.1.fc1.lora_E"].shape == (12, 1)
+        assert sd["base_model.model.model.encoder.layers.1.fc1.lora_E"].abs().sum() > 0
+        assert json.load(open(os.path.join(ck, "adapter_config.json")))["peft_type"] == "ADALORA"
+    else:
+        assert "base_model.model.model.encoder.layers.0.self_attn.q_proj.lora_A.weight" in sd
+        assert sd["base_model.model.model.encoder.layers.1.fc2.lora_B.weight"].abs().sum() > 0   # B left its zero init
     assert "base_model.model.model.encoder.conv1.0.weight" in sd and sd["base_model.model.model.encoder.conv1.0.weight"].shape == (256, 20, 3)
-    assert sd["base_model.model.model.encoder.layers.1.fc2.lora_B.weight"].abs().sum() > 0   # B left its zero init
     evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
                      "--max_new_tokens=8"] + common)
     res = json.load(open(os.path.join(ck, "formal_test_resultsno_post_processing.json")))
@@ -79,3 +86,46 @@ def test_module_api_loss_backward_matches_engine(dev):
         b = merged(input_features=x, labels=labels)
     assert abs(a.loss.item() - b.loss.item()) < 5e-3
     torch.testing.assert_close(a.logits.float(), b.logits.float(), atol=3e-2, rtol=3e-2)
+
+
+def test_adalora_module_api_grads_and_merge(dev):
+    """AdaLoRA through the nn.Module surface: rank-12 parameters are views of the engine's rank-16 padded buffer,
+    `.loss.backward()` hands out A/B/E gradients, merge_and_unload reproduces the adapted forward."""
+    from neuspeech1_amd.peft_compat import AdaLoraConfig, get_peft_model
+    from neuspeech1_amd.weights import TINY, synth_batch
+    from utils.load_model import WhisperForConditionalGeneration, match_modules_string
+    from utils.model_utils import projection_module
+    torch.manual_seed(0)
+    model = WhisperForConditionalGeneration.from_pretrained("synthetic:tiny", device_map="auto")
+    model.model.encoder.set_input_embeddings(projection_module(config_name="base", meg_ch=20, d_model=256).to(model.device))
+    for p in model.parameters():
+        p.requires_grad = False
+    t = match_modules_string(model.named_modules(), ["model.encoder"], ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"])
+    pm = get_peft_model(model, AdaLoraConfig(init_r=12, target_r=4, lora_alpha=32, lora_dropout=0.0, orth_reg_weight=0.5,
+                                             target_modules=t, modules_to_save=["model.encoder.conv1", "model.encoder.conv2"]))
+    with torch.no_grad():
+        for n, p in pm.named_parameters():
+            if "lora_E" in n:
+                p.normal_(0, 0.5)
+            elif "lora_B" in n:
+                p.normal_(0, 0.3)
+    x, labels = synth_batch(TINY, 2, 9)
+    x, labels = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    pm.train()
+    out = pm(input_features=x, labels=labels)
+    out.loss.backward()
+    named = dict(pm.named_parameters())
+    for k in ("lora_A", "lora_B", "lora_E"):
+        g = named[f"base_model.model.model.encoder.layers.1.self_attn.k_proj.{k}.default"].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, k
+    assert named["base_model.model.model.encoder.layers.0.fc2.lora_B.default"].shape == (256, 12)
+    pm.eval()
+    with torch.no_grad():
+        a = pm(input_features=x, labels=labels)
+        ev_loss = a.loss.item()
+        a_logits = a.logits.float().clone()
+        merged = pm.merge_and_unload()
+        b = merged(input_features=x, labels=labels)
+    assert out.loss.item() > ev_loss   # the training loss carries the orthogonality penalty, evaluation does not
+    assert abs(ev_loss - b.loss.item()) < 5e-3
+    torch.testing.assert_close(a_logits, b.logits.float(), atol=3e-2, rtol=3e-2)

@@ -158,3 +158,51 @@ def test_train_steps_reduce_loss_and_match_oracle_update(dev):
     got = eng2.pview("model.encoder.conv2.bias").cpu()
     big = gref.abs() > 1e-4 * gref.abs().max()   # step-1 AdamW is ~sign(g): ignore near-zero gradients
     torch.testing.assert_close(got[big], pref[big], atol=2e-5, rtol=0)
+
+
+def test_adalora_forward_backward_vs_oracle(dev):
+    """AdaLoRA at its initial rank 12 (finetune.py:206-208): y += B((A x) * E) * 32/(12+1e-5), loss += 0.5 * orth-reg;
+    gradients of A, B, E and the conv stem against the oracle (rank padded to 16 inside the engine)."""
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    from oracle import whisper_meg_oracle as O
+    dims, r = TINY, 12
+    sd = make_state_dict(dims, 42)
+    lora_sd = make_lora_state(dims, r, adalora=True, b_std=0.3)
+    spec = LoraSpec(r=r, alpha=32.0, dropout=0.0, adalora=True, orth_reg_weight=0.5)
+    eng = MegWhisperEngine(dims, sd, lora=spec, lora_sd=lora_sd, train_cfg=TrainCfg(), device=dev)
+    x, labels = synth_batch(dims, 3, 11)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, spec.scale, orth_reg_weight=0.5)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss.item(), o_loss.item())
+    s = eng.loss_scale_dev.item()
+    d, f, rp = dims.d, dims.ffn, eng.r
+    bad = {}
+    for i in range(dims.enc_layers):
+        p = f"model.encoder.layers.{i}."
+        A3 = eng.gview(p + "self_attn.qkv.lora_A").view(3, rp, d).cpu() / s
+        E3 = eng.gview(p + "self_attn.qkv.lora_E").view(3, rp).cpu() / s
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            got = {"lora_A": A3[j, :r], "lora_B": eng.gview(p + f"self_attn.{nm}.lora_B").view(d, rp)[:, :r].cpu() / s,
+                   "lora_E": E3[j, :r].reshape(r, 1)}
+            for k, v in got.items():
+                e = rel(v, og[p + f"self_attn.{nm}.{k}.weight"])
+                if not e < 3e-2:
+                    bad[p + nm + k] = e
+            assert A3[j, r:].abs().max() == 0, "padded ranks must stay dead"
+        for nm, no, ki in (("self_attn.out_proj", d, d), ("fc1", f, d), ("fc2", d, f)):
+            got = {"lora_A": eng.gview(p + nm + ".lora_A").view(rp, ki)[:r].cpu() / s,
+                   "lora_B": eng.gview(p + nm + ".lora_B").view(no, rp)[:, :r].cpu() / s,
+                   "lora_E": eng.gview(p + nm + ".lora_E")[:r].reshape(r, 1).cpu() / s}
+            for k, v in got.items():
+                e = rel(v, og[p + nm + f".{k}.weight"])
+                if not e < 3e-2:
+                    bad[p + nm + k] = e
+    assert not bad, bad
+    assert rel(eng.conv_weight_grad("conv2").float().cpu() / s, og["model.encoder.conv2.weight"]) < 3e-2
+    # and it trains: E starts at zero in the reference, so only E moves at first; here all three move
+    l0 = eng.train_step(xd, ld).item()
+    l1 = [eng.train_step(xd, ld).item() for _ in range(3)][-1]
+    assert l1 < l0 and eng.found_inf_dev.item() == 0

@@ -233,8 +233,14 @@ class WhisperForConditionalGeneration(nn.Module):
         lora, lora_sd = None, None
         if self._peft is not None:
             pc = self._peft
-            lora = LoraSpec(r=pc.r, alpha=float(pc.lora_alpha), dropout=float(pc.lora_dropout))
-            lora_sd = {k.replace(".default", ""): v for k, v in sd.items() if ".lora_" in k}
+            ada = getattr(pc, "peft_type", "LORA") == "ADALORA"
+            lora = LoraSpec(r=pc.init_r if ada else pc.r, alpha=float(pc.lora_alpha), dropout=float(pc.lora_dropout),
+                            adalora=ada, orth_reg_weight=float(getattr(pc, "orth_reg_weight", 0.0)) if ada else 0.0)
+            lora_sd = {}
+            for k, v in sd.items():
+                if ".lora_" in k:
+                    k = k.replace(".default", "")
+                    lora_sd[k if k.endswith(".weight") else k + ".weight"] = v
         eng = MegWhisperEngine(self.dims(), sd, lora=lora, lora_sd=lora_sd, train_cfg=self.train_cfg or TrainCfg(),
                                device=self.device)
         self._engine = eng
@@ -248,18 +254,31 @@ class WhisperForConditionalGeneration(nn.Module):
             mod.bias.data = eng.pview(f"model.encoder.{name}.bias")
         if self._peft is None:
             return
-        d, f, r = eng.dims.d, eng.dims.ffn, eng.r
-        for i, layer in enumerate(enc.layers):
+        for par, view in self._adapter_views(eng, eng.pview):
+            par.data = view
+
+    def _adapter_views(self, eng, getv):
+        """(parameter, view of the engine's flat buffer) for every adapter tensor.  The engine pads the rank to a
+        multiple of 16 (eng.r) and keeps q|k|v down-projections stacked; the parameters see the live r rows/columns."""
+        d, f, rp, r = eng.dims.d, eng.dims.ffn, eng.r, eng.r_real
+        ada = eng.adalora
+        W = (lambda m, t: getattr(m, t)["default"]) if ada else (lambda m, t: getattr(m, t)["default"].weight)
+        for i, layer in enumerate(self.model.encoder.layers):
             p = f"model.encoder.layers.{i}."
-            A = eng.pview(p + "self_attn.qkv.lora_A").view(3, r, d)
+            A = getv(p + "self_attn.qkv.lora_A").view(3, rp, d)
+            E = getv(p + "self_attn.qkv.lora_E").view(3, rp) if ada else None
             for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
                 m = getattr(layer.self_attn, nm)
-                m.lora_A["default"].weight.data = A[j]
-                m.lora_B["default"].weight.data = eng.pview(p + f"self_attn.{nm}.lora_B").view(d, r)
+                yield W(m, "lora_A"), A[j, :r]
+                yield W(m, "lora_B"), getv(p + f"self_attn.{nm}.lora_B").view(d, rp)[:, :r]
+                if ada:
+                    yield W(m, "lora_E"), E[j, :r].unsqueeze(1)
             for nm, m, no, ki in (("self_attn.out_proj", layer.self_attn.out_proj, d, d), ("fc1", layer.fc1, f, d),
                                   ("fc2", layer.fc2, d, f)):
-                m.lora_A["default"].weight.data = eng.pview(p + nm + ".lora_A").view(r, ki)
-                m.lora_B["default"].weight.data = eng.pview(p + nm + ".lora_B").view(no, r)
+                yield W(m, "lora_A"), getv(p + nm + ".lora_A").view(rp, ki)[:r]
+                yield W(m, "lora_B"), getv(p + nm + ".lora_B").view(no, rp)[:, :r]
+                if ada:
+                    yield W(m, "lora_E"), getv(p + nm + ".lora_E")[:r].unsqueeze(1)
 
     # ------------------------------------------------------------------ forward / generate
     def forward(self, input_features=None, attention_mask=None, decoder_input_ids=None, labels=None, **_):
@@ -353,18 +372,8 @@ def _grad_views(self, eng):
         out[mod.weight.data_ptr()] = eng.conv_weight_grad(name)
         out[mod.bias.data_ptr()] = eng.gview(f"model.encoder.{name}.bias")
     if self._peft is not None:
-        d, f, r = eng.dims.d, eng.dims.ffn, eng.r
-        for i, layer in enumerate(enc.layers):
-            p = f"model.encoder.layers.{i}."
-            A = eng.gview(p + "self_attn.qkv.lora_A").view(3, r, d)
-            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
-                m = getattr(layer.self_attn, nm)
-                out[m.lora_A["default"].weight.data_ptr()] = A[j]
-                out[m.lora_B["default"].weight.data_ptr()] = eng.gview(p + f"self_attn.{nm}.lora_B").view(d, r)
-            for nm, m, no, ki in (("self_attn.out_proj", layer.self_attn.out_proj, d, d), ("fc1", layer.fc1, f, d),
-                                  ("fc2", layer.fc2, d, f)):
-                out[m.lora_A["default"].weight.data_ptr()] = eng.gview(p + nm + ".lora_A").view(r, ki)
-                out[m.lora_B["default"].weight.data_ptr()] = eng.gview(p + nm + ".lora_B").view(no, r)
+        for par, view in self._adapter_views(eng, eng.gview):
+            out[par.data_ptr()] = view
     return out
 
 
