@@ -128,7 +128,7 @@ def main():
         dom = "nt256" if "nt256" in tot else "nt128"
         fl, sec, n = tot[dom]
         ach = fl / sec / 1e12
-        roof = {"bound": "mfma", "kernel": "ns_gemm_ring256_kernel" if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
+        roof = {"bound": "mfma", "kernel": "ns_gemm_p8_kernel" if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                 "traffic": None, "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                 "gflop_per_launch": round(fl / n / 1e9, 2),

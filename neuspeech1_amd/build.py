@@ -18,6 +18,7 @@ LIB = os.path.join(HERE, "libneuspeech_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
+FLAGS += os.environ.get("NS_EXTRA_HIPCC_FLAGS", "").split()   # diagnostic builds only (e.g. -DNS_P8_STAMPS)
 
 
 def sources():

@@ -414,6 +414,7 @@ void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
+int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -468,10 +469,17 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   } else if (skinny) {
     if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
-    // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the 256^2 ring
+    // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the one-barrier 256^2 ring,
+    // 4 = force the phase-interleaved 256^2 kernel where it applies, 5 = auto without the phase-interleaved kernel
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    const bool big = g_use_ring == 3 || (g_use_ring == 1 && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
-    if (big) ns_gemm_ring256_launch(d, st); else ns_gemm_ring_launch(d, st);
+    const bool big = g_use_ring == 3 || g_use_ring == 4 ||
+                     ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
+    const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
+                       (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
+                       (!d->H32 || d->h32m.ld % 8 == 0);
+    if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1)) ns_gemm_p8_launch(d, st);
+    else if (big) ns_gemm_ring256_launch(d, st);
+    else ns_gemm_ring_launch(d, st);
   } else {
     if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);
   }
