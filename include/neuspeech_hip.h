@@ -255,6 +255,15 @@ typedef struct {
 } ns_logits_proc_desc;
 int ns_logits_process(const ns_logits_proc_desc* d, void* stream);
 
+/* ns_logits_process + per-row top-k fused, without materialising the fp32 score matrix (d->scores32 is ignored):
+ * cand_vals / cand_idx (rows x k) receive each row's k best processed scores, ordered (value desc, column asc), with
+ * cand_idx = (row % group_rows) * V + column -- the flat index HF's beam search takes its top-2*beams over
+ * (HF:generation/utils.py:3409-3417).  Values and order are bit-identical to ns_logits_process followed by a top-k.
+ * ns_topk_merge then reduces each group's ncand = group_rows * k candidates to its k best (same ordering). */
+int ns_logits_select(const ns_logits_proc_desc* d, int k, int group_rows, float* cand_vals, int* cand_idx, void* stream);
+int ns_topk_merge(const float* cand_vals, const int* cand_idx, int groups, int ncand, int k, float* vals, int* idx,
+                  void* stream);
+
 /* top-k (k <= 16) of each group of n contiguous floats, ordered (value desc, index asc); two-stage (per-chunk
  * candidates in `workspace`, then a merge) */
 size_t ns_topk_workspace_bytes(int groups, long long n, int k);
@@ -278,9 +287,10 @@ typedef struct {
 int ns_beam_update(const ns_beam_desc* d, void* stream);
 int ns_anc_update(const int* anc_in, int* anc_out, const int* parent, int rows, int ld, int cur, const int* cur_dev,
                   void* stream);
-/* greedy: argmax of processed scores, finished rows emit pad (HF:generation/utils.py:2897-2960) */
+/* greedy: argmax of processed scores (or best_idx[row] from ns_logits_select with k = 1, scores may then be NULL),
+ * finished rows emit pad (HF:generation/utils.py:2897-2960) */
 int ns_greedy_update(const float* scores, int rows, int V, int64_t* seqs, int ld, int cur, const int* cur_dev, int eos,
-                     int pad, unsigned char* done, int* any_open, int64_t* next_tok, void* stream);
+                     int pad, unsigned char* done, int* any_open, int64_t* next_tok, const int* best_idx, void* stream);
 
 #ifdef __cplusplus
 }

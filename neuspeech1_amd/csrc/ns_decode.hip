@@ -41,21 +41,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
   auto krow = [&](int j) -> long long {
     return anc ? (long long)j * p.kv_pos_stride + anc[j] : (long long)grp * p.kv_group_stride + j;
   };
-  // ---- scores
-  for (int j = sg; j < Lk; j += 32) {
-    const half8 kv = *(const half8*)(Kb + krow(j) * p.ldk);
-    float kf[8];
+  // ---- scores.  KU keys per 8-lane subgroup and iteration: KU independent 16-B loads in flight per lane (a single
+  // load per iteration leaves the kernel latency-bound at ~3.5 TB/s on the 393 MB/layer cross K/V stream)
+  constexpr int KU = 4;
+  for (int j0 = sg * KU; j0 < Lk; j0 += 32 * KU) {
+    half8 kv[KU];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) kf[e] = (float)kv[e];
+    for (int u = 0; u < KU; ++u) kv[u] = *(const half8*)(Kb + krow(min(j0 + u, Lk - 1)) * p.ldk);
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-      float s = 0.f;
+    for (int u = 0; u < KU; ++u) {
+      float kf[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += q[qi][e] * kf[e];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (l8 == 0) sc[qi * lkp + j] = s;
+      for (int e = 0; e < 8; ++e) kf[e] = (float)kv[u][e];
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += q[qi][e] * kf[e];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (l8 == 0 && j0 + u < Lk) sc[qi * lkp + j0 + u] = s;
+      }
     }
   }
   __syncthreads();
@@ -80,16 +87,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
   for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
-  for (int j = sg; j < Lk; j += 32) {
-    const half8 vv = *(const half8*)(Vb + krow(j) * p.ldv);
-    float vf[8];
+  for (int j0 = sg * KU; j0 < Lk; j0 += 32 * KU) {
+    half8 vv[KU];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vf[e] = (float)vv[e];
+    for (int u = 0; u < KU; ++u) vv[u] = *(const half8*)(Vb + krow(min(j0 + u, Lk - 1)) * p.ldv);
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-      const float pj = sc[qi * lkp + j];
+    for (int u = 0; u < KU; ++u) {
+      if (j0 + u >= Lk) break;
+      float vf[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[qi][e] += pj * vf[e];
+      for (int e = 0; e < 8; ++e) vf[e] = (float)vv[u][e];
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const float pj = sc[qi * lkp + j0 + u];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[qi][e] += pj * vf[e];
+      }
     }
   }
   // reduce over the 8 subgroups of the wave, then over the 4 waves through LDS
@@ -254,6 +267,184 @@ __global__ __launch_bounds__(256) void topk_stage2_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused select
+// logits_process + per-row top-k without the fp32 score matrix.  Four streaming passes over the fp16 row with 16-B
+// loads (max, sum-exp, per-thread max, candidate collection): the first comes from HBM, the rest from L2 / Infinity
+// Cache; nothing but k (value, column) pairs per row is written.  The processors touch few columns, so they go to
+// an LDS patch list (+ bitmaps of overridden / banned columns) and every other column keeps its raw logit:
+// (raw - lse) + beam_score is monotone in raw, so the selection compares raw values and only the winners are
+// transformed -- with exactly the arithmetic of logits_process_kernel, so values and order are bit-identical.
+// Selection: T = k-th largest of the 256 per-thread maxima is a lower bound of the row's k-th largest value; the
+// candidates are every un-overridden column with raw >= T (typically k..k+2 of them) plus the finite patch entries;
+// k block-argmax rounds over that short list give the result (value desc, column asc).
+constexpr int SEL_MAX_LDV = 26 * 256 * 8;   // bitmap capacity (53,248 columns)
+constexpr int SEL_CAP = 1024;               // candidate / patch list capacity
+constexpr int SEL_WORDS = SEL_MAX_LDV / 32;
+
+__global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc_desc p, int k, int group_rows,
+                                                            float* __restrict__ cand_vals, int* __restrict__ cand_idx) {
+  __shared__ uint32_t ovr[SEL_WORDS], inf[SEL_WORDS];
+  __shared__ float pval[SEL_CAP], cval[SEL_CAP];
+  __shared__ int pcol[SEL_CAP], ccol[SEL_CAP];
+  __shared__ float sh[4], shv[4];
+  __shared__ int shi[4];
+  __shared__ int npatch, ncand;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const half_t* lg = (const half_t*)p.logits16 + (long long)row * p.ldv;
+  const int64_t* ids = p.ids + (long long)row * p.ids_ld;
+  const int cur = p.cur_len_dev ? *p.cur_len_dev : p.cur_len;
+  const int V = p.V, nvec = (V + 7) >> 3;
+  for (int i = tid; i < SEL_WORDS; i += 256) { ovr[i] = 0u; inf[i] = 0u; }
+  if (tid == 0) { npatch = 0; ncand = 0; }
+
+  float lse = 0.f;
+  if (p.log_softmax) {
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int vi = tid; vi < nvec; vi += 256) {
+      const half8 v = *(const half8*)(lg + (long long)vi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (vi * 8 + e < V) mx = fmaxf(mx, (float)v[e]);
+    }
+    mx = blk_reduce(mx, true, sh);
+    float se = 0.f;
+#pragma unroll 4
+    for (int vi = tid; vi < nvec; vi += 256) {
+      const half8 v = *(const half8*)(lg + (long long)vi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (vi * 8 + e < V) se += __expf((float)v[e] - mx);
+    }
+    se = blk_reduce(se, false, sh);
+    lse = mx + __logf(se);
+  }
+  __syncthreads();
+  const float bs = p.beam_scores ? p.beam_scores[row] : 0.f;
+  auto finalv = [&](float raw) __attribute__((always_inline)) -> float {
+    float o = raw - lse;
+    if (p.beam_scores) o += bs;
+    return o;
+  };
+  // ---- processors -> bitmaps + patch list (same order / semantics as logits_process_kernel)
+  if (p.repetition_penalty != 1.f) {
+    for (int t = tid; t < cur; t += 256) {
+      const int64_t tok = ids[t];
+      if (tok >= 0 && tok < V) {
+        const uint32_t bit = 1u << (tok & 31);
+        if (!(atomicOr(&ovr[tok >> 5], bit) & bit)) {          // first occurrence only: duplicates carry the same value
+          const float b = (float)lg[tok] - lse;
+          const int pos = atomicAdd(&npatch, 1);
+          if (pos < SEL_CAP) { pcol[pos] = (int)tok; pval[pos] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty; }
+        }
+      }
+    }
+  }
+  auto ban = [&](long long c) __attribute__((always_inline)) {
+    if (c >= 0 && c < V) { atomicOr(&ovr[c >> 5], 1u << (c & 31)); atomicOr(&inf[c >> 5], 1u << (c & 31)); }
+  };
+  const int n = p.no_repeat_ngram;
+  if (n > 0 && cur + 1 >= n) {
+    for (int s0 = tid; s0 + n - 1 < cur; s0 += 256) {
+      bool match = true;
+      for (int e = 0; e < n - 1; ++e) match = match && (ids[s0 + e] == ids[cur - (n - 1) + e]);
+      if (match) ban(ids[s0 + n - 1]);
+    }
+  }
+  for (int i = tid; i < p.n_suppress; i += 256) ban(p.suppress[i]);
+  if (cur == p.begin_index)
+    for (int i = tid; i < p.n_begin_suppress; i += 256) ban(p.begin_suppress[i]);
+  __syncthreads();
+
+  // ---- per-thread maximum of the un-overridden columns, T = k-th largest of the 256 maxima
+  float mloc = -INFINITY;
+#pragma unroll 4
+  for (int vi = tid; vi < nvec; vi += 256) {
+    const half8 v = *(const half8*)(lg + (long long)vi * 8);
+    const int c0 = vi * 8;
+    const uint32_t m8 = (ovr[c0 >> 5] >> (c0 & 31)) & 0xFFu;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e < V && !((m8 >> e) & 1u)) mloc = fmaxf(mloc, (float)v[e]);
+  }
+  float T = -INFINITY;
+  {
+    float mine = mloc;
+    for (int t = 0; t < k; ++t) {
+      float bv = mine;
+      int bi = tid;
+      blk_argmax_after(bv, bi, shv, shi);
+      T = bv;
+      if (bi == tid) mine = -INFINITY;
+      __syncthreads();
+    }
+  }
+  // ---- candidates: raw >= T (un-overridden) + finite patch entries, in final-value space
+  if (mloc >= T && mloc > -INFINITY) {     // threads whose maximum is below T hold no candidate: skip their re-read
+    for (int vi = tid; vi < nvec; vi += 256) {
+      const half8 v = *(const half8*)(lg + (long long)vi * 8);
+      const int c0 = vi * 8;
+      const uint32_t m8 = (ovr[c0 >> 5] >> (c0 & 31)) & 0xFFu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float raw = (float)v[e];
+        if (c0 + e < V && !((m8 >> e) & 1u) && raw >= T) {
+          const int pos = atomicAdd(&ncand, 1);
+          if (pos < SEL_CAP) { ccol[pos] = c0 + e; cval[pos] = finalv(raw); }
+        }
+      }
+    }
+  }
+  const int np = min(npatch, SEL_CAP);
+  for (int i = tid; i < np; i += 256) {
+    const int c = pcol[i];
+    if (!((inf[c >> 5] >> (c & 31)) & 1u)) {
+      const int pos = atomicAdd(&ncand, 1);
+      if (pos < SEL_CAP) { ccol[pos] = c; cval[pos] = p.beam_scores ? pval[i] + bs : pval[i]; }
+    }
+  }
+  __syncthreads();
+  const bool overflow = ncand > SEL_CAP || npatch > SEL_CAP;
+  const int nc = min(ncand, SEL_CAP);
+  const int gbase = (row % group_rows) * V;
+  float pv = INFINITY;
+  int pi = -1;
+  for (int t = 0; t < k; ++t) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (!overflow) {
+      for (int i = tid; i < nc; i += 256) {
+        const float v = cval[i];
+        const int c = ccol[i];
+        const bool after = (v < pv) || (v == pv && c > pi);
+        if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+      }
+    } else {
+      // lists overflowed (pathological rows: hundreds of ties, or a prompt longer than the list): exact slow path,
+      // k full passes over the row in final-value space
+#pragma unroll 1
+      for (int c = tid; c < V; c += 256) {
+        float v;
+        if ((inf[c >> 5] >> (c & 31)) & 1u) v = -INFINITY;
+        else if ((ovr[c >> 5] >> (c & 31)) & 1u) {
+          const float b = (float)lg[c] - lse;
+          v = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+          if (p.beam_scores) v += bs;
+        } else v = finalv((float)lg[c]);
+        const bool after = (v < pv) || (v == pv && c > pi);
+        if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+      }
+    }
+    blk_argmax_after(bv, bi, shv, shi);
+    if (tid == 0) {
+      cand_vals[(long long)row * k + t] = bv;
+      cand_idx[(long long)row * k + t] = bi == 0x7fffffff ? 0x7fffffff : gbase + bi;
+    }
+    pv = bv; pi = bi;
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- beam bookkeeping
 __global__ __launch_bounds__(256) void beam_update_kernel(const ns_beam_desc p) {
   const int b = blockIdx.x, nb = p.num_beams, K2 = 2 * nb, ML = p.max_len;
@@ -351,14 +542,14 @@ __global__ void anc_update_kernel(const int* __restrict__ anc_in, int* __restric
 __global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restrict__ scores, int V, int64_t* __restrict__ seqs,
                                                             int ld, int cur, const int* cur_dev, int eos, int pad,
                                                             unsigned char* __restrict__ done, int* __restrict__ any_open,
-                                                            int64_t* __restrict__ next_tok) {
+                                                            int64_t* __restrict__ next_tok, const int* __restrict__ best_idx) {
   __shared__ float shv[4];
   __shared__ int shi[4];
   const int row = blockIdx.x;
   const float* s = scores + (long long)row * V;
   float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int c = threadIdx.x; c < V; c += 256) {
+  int bi = best_idx ? best_idx[row] : 0x7fffffff;
+  for (int c = threadIdx.x; c < (best_idx ? 0 : V); c += 256) {
     const float v = s[c];
     if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
   }
@@ -372,7 +563,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w)
-      if (shv[w] > bv || (shv[w] == bv && shi[w] < bi)) { bv = shv[w]; bi = shi[w]; }
+      if (!best_idx && (shv[w] > bv || (shv[w] == bv && shi[w] < bi))) { bv = shv[w]; bi = shi[w]; }
     const int c = cur_dev ? *cur_dev : cur;
     int tok = done[row] ? pad : bi;
     seqs[(long long)row * ld + c] = tok;
@@ -439,6 +630,28 @@ extern "C" int ns_topk_groups(const float* x, int groups, long long n, int k, fl
   return NS_OK;
 }
 
+extern "C" int ns_logits_select(const ns_logits_proc_desc* d, int k, int group_rows, float* cand_vals, int* cand_idx,
+                                void* stream) {
+  NS_CHECK_ARG(d && d->logits16 && d->ids && cand_vals && cand_idx, "ns_logits_select: null pointer");
+  NS_CHECK_ARG(d->rows > 0 && d->V > 0 && d->ldv >= d->V && d->ldv % 8 == 0 && d->ldv <= SEL_MAX_LDV,
+               "ns_logits_select: ldv=%d must be a multiple of 8 and <= %d (use ns_logits_process + ns_topk_groups beyond)",
+               d->ldv, SEL_MAX_LDV);
+  NS_CHECK_ARG(k >= 1 && k <= 16 && group_rows >= 1 && d->cur_len >= 0 && d->cur_len <= d->ids_ld, "ns_logits_select: bad shape");
+  NS_CHECK_ARG(d->n_suppress == 0 || d->suppress, "ns_logits_select: suppress list missing");
+  NS_CHECK_ARG(d->n_begin_suppress == 0 || d->begin_suppress, "ns_logits_select: begin_suppress list missing");
+  hipLaunchKernelGGL(logits_select_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)stream, *d, k, group_rows, cand_vals, cand_idx);
+  NS_CHECK_LAUNCH("ns_logits_select");
+  return NS_OK;
+}
+
+extern "C" int ns_topk_merge(const float* cand_vals, const int* cand_idx, int groups, int ncand, int k, float* vals, int* idx,
+                             void* stream) {
+  NS_CHECK_ARG(cand_vals && cand_idx && vals && idx && groups > 0 && ncand > 0 && k >= 1 && k <= 16, "ns_topk_merge: bad arguments");
+  hipLaunchKernelGGL(topk_stage2_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, cand_vals, cand_idx, ncand, k, vals, idx);
+  NS_CHECK_LAUNCH("ns_topk_merge");
+  return NS_OK;
+}
+
 extern "C" int ns_beam_update(const ns_beam_desc* d, void* stream) {
   NS_CHECK_ARG(d && d->top_vals && d->top_idx && d->run_seqs_in && d->run_seqs_out && d->fin_seqs_in && d->fin_seqs_out &&
                    d->open && d->any_open && d->any_continuation, "ns_beam_update: null pointer");
@@ -458,10 +671,11 @@ extern "C" int ns_anc_update(const int* anc_in, int* anc_out, const int* parent,
 }
 
 extern "C" int ns_greedy_update(const float* scores, int rows, int V, int64_t* seqs, int ld, int cur, const int* cur_dev, int eos,
-                                int pad, unsigned char* done, int* any_open, int64_t* next_tok, void* stream) {
-  NS_CHECK_ARG(scores && seqs && done && any_open && next_tok && rows > 0 && V > 0, "ns_greedy_update: bad arguments");
-  hipLaunchKernelGGL(greedy_update_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, V, seqs, ld, cur, cur_dev, eos,
-                     pad, done, any_open, next_tok);
+                                int pad, unsigned char* done, int* any_open, int64_t* next_tok, const int* best_idx,
+                                void* stream) {
+  NS_CHECK_ARG((scores || best_idx) && seqs && done && any_open && next_tok && rows > 0 && V > 0, "ns_greedy_update: bad arguments");
+  hipLaunchKernelGGL(greedy_update_kernel, dim3(rows), dim3(best_idx ? 64 : 256), 0, (hipStream_t)stream, scores, V, seqs, ld, cur,
+                     cur_dev, eos, pad, done, any_open, next_tok, best_idx);
   NS_CHECK_LAUNCH("ns_greedy_update");
   return NS_OK;
 }

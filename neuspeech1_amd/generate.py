@@ -6,7 +6,11 @@ Design notes (MI355X-first):
   * the self-attention cache is laid out [position][slot]; beams are reordered by rewriting a small int32
     ancestry table (which slot holds my token-p K/V) instead of index_select-ing every cache tensor;
   * logits processors, top-2k selection and the HF beam bookkeeping run on the device; the host only polls a
-    two-word flag every `check_every` steps.
+    two-word flag every `check_every` steps;
+  * a decode iteration is ~160 small launches, so after one eager iteration the two halves of an iteration
+    ("select the next token", "feed it through the decoder") are captured as hipGraphs -- one pair per ping-pong
+    parity -- and replayed; the position / length the kernels need comes from device counters the graph itself
+    advances (the C ABI's *_dev arguments), never from launch arguments.
 """
 from __future__ import annotations
 
@@ -19,8 +23,13 @@ F16, F32 = torch.float16, torch.float32
 
 
 class Generator:
-    def __init__(self, engine):
+    def __init__(self, engine, use_graph: bool = True, graph_min_steps: int = 24):
         self.eng = engine
+        self.use_graph = use_graph
+        # capturing the four graphs costs ~3-4 ms; measured on MI355X the decode loop is GPU-bound (B=128: replay and
+        # eager launches give the same tokens/s), so graphs only insure against a slow / contended host and are
+        # skipped for short generations
+        self.graph_min_steps = graph_min_steps
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
@@ -61,20 +70,28 @@ class Generator:
         gf = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
         st = (torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
         logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
-        scores = torch.empty(Bp, V, device=dev, dtype=F32)
+        fused_select = Vp <= ops.SELECT_MAX_LDV      # processors + per-row top-k in one pass, no fp32 score matrix
+        scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
 
-        def step(tok: torch.Tensor, t: int, parent):
-            """Feed token `tok` (Bp,) at position t; leaves last-position logits in `logits`."""
-            ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t)
+        def step(tok: torch.Tensor, t: int, parent, ctr=None, idx64=None):
+            """Feed token `tok` (Bp,) at position t; leaves last-position logits in `logits`.
+            With `ctr` (device int32 [t, t+1]) / `idx64` (device int64 [t]) the position is read on the device."""
+            c0 = ctr
+            c1 = (ctr, 1) if ctr is not None else None
+            ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t, cur_dev=c0)
             anc.reverse()
             a = anc[0]
-            ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t)
+            ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t, pos0_dev=c0)
             for li, Lw in enumerate(eng.dec):
                 ops.layernorm_fwd(h[0], *Lw["ln1"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["qkv"], C16=qkv)
-                kvc[li].view(max_len, Bp, 2 * d)[t].copy_(qkv[:, d:])
+                if idx64 is None:
+                    kvc[li].view(max_len, Bp, 2 * d)[t].copy_(qkv[:, d:])
+                else:
+                    kvc[li].view(max_len, Bp, 2 * d).index_copy_(0, idx64, qkv[:, d:].unsqueeze(0))
                 ops.attn_decode(Q=qkv, K=kvc[li], V=(kvc[li], d), O=ao, groups=Bp, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
-                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a, anc_ld=max_len, kv_pos_stride=Bp)
+                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a, anc_ld=max_len, kv_pos_stride=Bp,
+                                kv_len_dev=c1)
                 eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
                 ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["cq"], C16=qc)
@@ -103,18 +120,70 @@ class Generator:
         next_tok = torch.empty(Bp, device=dev, dtype=torch.int64)
         cur = P
 
-        if nb == 1:
-            done = torch.zeros(Bp, device=dev, dtype=torch.uint8)
+        graph_ok = self.use_graph and dev.type == "cuda"
+
+        def run_loop(select, ping_pong):
+            """select(cur, ctr) picks token `cur` from `logits` (and reverses the lists in `ping_pong`); the step then
+            feeds it at position `cur`.  First iteration eager (lazy kernel attributes / workspaces), then graphs."""
+            nonlocal cur
+            n_sel = 0
+            ctr = idx64 = None
+            graphs = None
             while cur < max_len:
-                ops.logits_process(ids=seqs[0], cur_len=cur, log_softmax=False, **proc)
-                flags.zero_()
-                ops.greedy_update(scores, Bp, V, seqs[0], max_len, cur, eos, pad, done, flags, next_tok)
+                if graphs is None:
+                    select(cur, None)
+                else:
+                    graphs[(n_sel - 1) & 1][0].replay()
+                n_sel += 1
                 cur += 1
                 if cur >= max_len:
                     break
-                if (cur - P) % check_every == 0 and flags[0].item() == 0:
-                    break
-                step(next_tok, cur - 1, None)
+                if (cur - P) % check_every == 0:
+                    f = flags.tolist()
+                    if f[0] == 0 or (nb > 1 and f[1] == 0):
+                        break
+                if graphs is None:
+                    step(next_tok, cur - 1, parent)
+                    if graph_ok and max_len - cur >= self.graph_min_steps:
+                        # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
+                        ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
+                        idx64 = torch.tensor([cur], device=dev, dtype=torch.int64)
+                        graphs = []
+                        torch.cuda.synchronize()
+                        for _ in range(2):
+                            gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(gs):
+                                select(cur, ctr)
+                            with torch.cuda.graph(gt):
+                                step(next_tok, cur, parent, ctr, idx64)
+                                ctr.add_(1)
+                                idx64.add_(1)
+                            graphs.append((gs, gt))
+                else:
+                    graphs[(n_sel - 2) & 1][1].replay()
+            if graphs is not None and (n_sel - 1) & 1:
+                for pair in ping_pong:      # replays do not touch the host-side lists: re-apply the odd reversal
+                    pair.reverse()
+
+        if nb == 1:
+            done = torch.zeros(Bp, device=dev, dtype=torch.uint8)
+            parent = None
+
+            cand_v = torch.empty(Bp, device=dev, dtype=F32)
+            cand_i = torch.empty(Bp, device=dev, dtype=torch.int32)
+
+            def select(c, ctr):
+                flags.zero_()
+                if fused_select:
+                    ops.logits_select(ids=seqs[0], cur_len=c, log_softmax=False, cur_len_dev=ctr, k=1, group_rows=1,
+                                      cand_vals=cand_v, cand_idx=cand_i, **proc)
+                    ops.greedy_update(None, Bp, V, seqs[0], max_len, c, eos, pad, done, flags, next_tok, cur_dev=ctr,
+                                      best_idx=cand_i)
+                else:
+                    ops.logits_process(ids=seqs[0], cur_len=c, log_softmax=False, cur_len_dev=ctr, **proc)
+                    ops.greedy_update(scores, Bp, V, seqs[0], max_len, c, eos, pad, done, flags, next_tok, cur_dev=ctr)
+
+            run_loop(select, [])
             out = seqs[0]
         else:
             run_scores = [torch.zeros(B, nb, device=dev, dtype=F32) for _ in range(2)]
@@ -126,27 +195,31 @@ class Generator:
             top_v = torch.empty(B, 2 * nb, device=dev, dtype=F32)
             top_i = torch.empty(B, 2 * nb, device=dev, dtype=torch.int32)
             parent = torch.empty(Bp, device=dev, dtype=torch.int32)
-            while True:
-                ops.logits_process(ids=seqs[0], cur_len=cur, log_softmax=True, beam_scores=run_scores[0], **proc)
-                ops.topk_groups(scores, B, nb * V, 2 * nb, top_v, top_i)
+            pairs = [seqs, run_scores, fin_seqs, fin_scores, fin_done]
+
+            cand_v = torch.empty(Bp, 2 * nb, device=dev, dtype=F32)
+            cand_i = torch.empty(Bp, 2 * nb, device=dev, dtype=torch.int32)
+
+            def select(c, ctr):
+                if fused_select:
+                    ops.logits_select(ids=seqs[0], cur_len=c, log_softmax=True, beam_scores=run_scores[0], cur_len_dev=ctr,
+                                      k=2 * nb, group_rows=nb, cand_vals=cand_v, cand_idx=cand_i, **proc)
+                    ops.topk_merge(cand_v, cand_i, B, nb * 2 * nb, 2 * nb, top_v, top_i)
+                else:
+                    ops.logits_process(ids=seqs[0], cur_len=c, log_softmax=True, beam_scores=run_scores[0], cur_len_dev=ctr, **proc)
+                    ops.topk_groups(scores, B, nb * V, 2 * nb, top_v, top_i)
                 flags.zero_()
                 ops.beam_update(top_vals=top_v, top_idx=top_i, run_seqs_in=seqs[0], run_seqs_out=seqs[1],
                                 run_scores_out=run_scores[1], fin_seqs_in=fin_seqs[0], fin_seqs_out=fin_seqs[1],
                                 fin_scores_in=fin_scores[0], fin_scores_out=fin_scores[1], fin_done_in=fin_done[0],
                                 fin_done_out=fin_done[1], open=open_row, parent_out=parent, next_tok_out=next_tok,
-                                any_open=flags, any_continuation=(flags, 1), cur_len_dev=None, batch=B, num_beams=nb,
-                                V=V, max_len=max_len, cur_len=cur, prompt_len=P, eos_id=eos,
+                                any_open=flags, any_continuation=(flags, 1), cur_len_dev=ctr, batch=B, num_beams=nb,
+                                V=V, max_len=max_len, cur_len=c, prompt_len=P, eos_id=eos,
                                 length_penalty=float(length_penalty))
-                for pair in (seqs, run_scores, fin_seqs, fin_scores, fin_done):
+                for pair in pairs:
                     pair.reverse()
-                cur += 1
-                if cur >= max_len:
-                    break
-                if (cur - P) % check_every == 0:
-                    f = flags.tolist()
-                    if f[0] == 0 or f[1] == 0:
-                        break
-                step(next_tok, cur - 1, parent)
+
+            run_loop(select, pairs)
             out = fin_seqs[0].view(B, nb, max_len)[:, 0]
             self.last_scores = fin_scores[0][:, 0].clone()
         # crop like HF: up to the longest hypothesis (a hypothesis ends at its first EOS after the prompt)

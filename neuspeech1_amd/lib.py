@@ -146,7 +146,9 @@ SIGNATURES = {
     "ns_topk_groups": (C.c_int, [_vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "ns_beam_update": (C.c_int, [C.POINTER(BeamDesc), _vp]),
     "ns_anc_update": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ns_greedy_update": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ns_greedy_update": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ns_logits_select": (C.c_int, [C.POINTER(LogitsProcDesc), _i, _i, _vp, _vp, _vp]),
+    "ns_topk_merge": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ns_grad_norm_workspace_bytes": (C.c_size_t, []),
     "ns_grad_norm": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "ns_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.POINTER(AdamWCfg), _vp, _vp, _vp, _vp, _vp, _vp]),

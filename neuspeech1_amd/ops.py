@@ -185,6 +185,25 @@ def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, be
     L.check(L.load().ns_logits_process(C.byref(d), _stream()), "ns_logits_process")
 
 
+SELECT_MAX_LDV = 26 * 256 * 8
+
+
+def logits_select(*, logits16, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, k, group_rows, cand_vals,
+                  cand_idx, beam_scores=None, repetition_penalty=1.0, no_repeat_ngram=0, suppress=None, n_suppress=0,
+                  begin_suppress=None, n_begin_suppress=0, cur_len_dev=None, scores32=None):
+    d = L.LogitsProcDesc()
+    d.logits16, d.scores32, d.ids, d.beam_scores = ptr(logits16), None, ptr(ids), ptr(beam_scores)
+    d.suppress, d.begin_suppress, d.cur_len_dev = ptr(suppress), ptr(begin_suppress), ptr(cur_len_dev)
+    d.rows, d.V, d.ldv, d.ids_ld, d.cur_len, d.begin_index = rows, V, ldv, ids_ld, cur_len, begin_index
+    d.n_suppress, d.n_begin_suppress, d.no_repeat_ngram, d.log_softmax = n_suppress, n_begin_suppress, no_repeat_ngram, int(log_softmax)
+    d.repetition_penalty = repetition_penalty
+    L.check(L.load().ns_logits_select(C.byref(d), k, group_rows, ptr(cand_vals), ptr(cand_idx), _stream()), "ns_logits_select")
+
+
+def topk_merge(cand_vals, cand_idx, groups, ncand, k, vals, idx):
+    L.check(L.load().ns_topk_merge(ptr(cand_vals), ptr(cand_idx), groups, ncand, k, ptr(vals), ptr(idx), _stream()), "ns_topk_merge")
+
+
 _topk_ws = {}
 
 
@@ -204,13 +223,14 @@ def beam_update(**kw):
     L.check(L.load().ns_beam_update(C.byref(d), _stream()), "ns_beam_update")
 
 
-def anc_update(anc_in, anc_out, parent, rows, ld, cur):
-    L.check(L.load().ns_anc_update(ptr(anc_in), ptr(anc_out), ptr(parent), rows, ld, cur, 0, _stream()), "ns_anc_update")
+def anc_update(anc_in, anc_out, parent, rows, ld, cur, cur_dev=None):
+    L.check(L.load().ns_anc_update(ptr(anc_in), ptr(anc_out), ptr(parent), rows, ld, cur, ptr(cur_dev), _stream()),
+            "ns_anc_update")
 
 
-def greedy_update(scores, rows, V, seqs, ld, cur, eos, pad, done, any_open, next_tok):
-    L.check(L.load().ns_greedy_update(ptr(scores), rows, V, ptr(seqs), ld, cur, 0, eos, pad, ptr(done), ptr(any_open),
-                                      ptr(next_tok), _stream()), "ns_greedy_update")
+def greedy_update(scores, rows, V, seqs, ld, cur, eos, pad, done, any_open, next_tok, cur_dev=None, best_idx=None):
+    L.check(L.load().ns_greedy_update(ptr(scores), rows, V, ptr(seqs), ld, cur, ptr(cur_dev), eos, pad, ptr(done), ptr(any_open),
+                                      ptr(next_tok), ptr(best_idx), _stream()), "ns_greedy_update")
 
 
 # ----------------------------------------------------------------------------- AdaLoRA

@@ -97,3 +97,62 @@ def test_processors_and_topk_kernels(dev):
     ops.topk_groups(scores, 2, 3 * V, 10, vals, idx)
     rv, ri = torch.topk(scores.view(2, 3 * V), 10, dim=1)
     assert torch.equal(vals, rv) and torch.equal(idx.long(), ri)
+
+
+@pytest.mark.parametrize("V,ldv,case", [(1000, 1024, "plain"), (51865, 51968, "plain"), (51865, 51968, "ties"),
+                                        (51865, 51968, "clustered")])
+def test_fused_select_is_bit_identical_to_process_plus_topk(dev, V, ldv, case):
+    """ns_logits_select + ns_topk_merge == ns_logits_process + ns_topk_groups: same values, same flat indices, same
+    order, including rows full of ties (fp16 logits) and rows whose top values sit in ONE thread's columns (the
+    candidate list overflows and the exact slow path runs)."""
+    from neuspeech1_amd import ops
+    torch.manual_seed(3)
+    nb, B, L, cur, k = 5, 3, 40, 23, 10
+    rows = nb * B
+    logits = torch.zeros(rows, ldv, device=dev, dtype=torch.float16)
+    if case == "ties":
+        logits[:, :V] = torch.randint(-4, 5, (rows, V), device=dev).half()           # nine distinct values
+    elif case == "clustered":
+        logits[:, :V] = (torch.randn(rows, V, device=dev)).half()
+        cols = (torch.arange(0, 24, device=dev)[:, None] * 2048 + torch.arange(0, 8, device=dev)[None, :]).reshape(-1) + 8 * 7
+        logits[:, cols[cols < V]] = (20 + torch.arange(0, (cols < V).sum(), device=dev) * 0.125).half()   # all in thread 7
+        logits[1, 5000:7000] = 30.0                                                  # > 1024 equal leaders
+    else:
+        logits[:, :V] = (torch.randn(rows, V, device=dev) * 3).half()
+    ids = torch.randint(0, min(V, 3000), (rows, L), device=dev)
+    ids[0, 3:5] = ids[0, cur - 2:cur]
+    ids[2, 10] = int(logits[2, :V].float().argmax())      # penalise the leader
+    bs = torch.randn(rows, device=dev)
+    sup = torch.tensor([5, 6, int(logits[4, :V].float().argmax())], device=dev, dtype=torch.int32)
+    common = dict(logits16=logits, ids=ids, rows=rows, V=V, ldv=ldv, ids_ld=L, cur_len=cur, begin_index=cur,
+                  repetition_penalty=5.0, no_repeat_ngram=2, suppress=sup, n_suppress=3, begin_suppress=sup, n_begin_suppress=1)
+    for lsm, beams in ((True, bs), (False, None)):
+        scores = torch.empty(rows, V, device=dev)
+        ops.logits_process(scores32=scores, log_softmax=lsm, beam_scores=beams, **common)
+        rv = torch.empty(B, k, device=dev)
+        ri = torch.empty(B, k, device=dev, dtype=torch.int32)
+        ops.topk_groups(scores, B, nb * V, k, rv, ri)
+        cv = torch.empty(rows, k, device=dev)
+        ci = torch.empty(rows, k, device=dev, dtype=torch.int32)
+        ops.logits_select(log_softmax=lsm, beam_scores=beams, k=k, group_rows=nb, cand_vals=cv, cand_idx=ci, **common)
+        gv = torch.empty(B, k, device=dev)
+        gi = torch.empty(B, k, device=dev, dtype=torch.int32)
+        ops.topk_merge(cv, ci, B, nb * k, k, gv, gi)
+        assert torch.equal(gv, rv), (case, lsm)
+        assert torch.equal(gi, ri), (case, lsm)
+        # per-row lists too (greedy uses k = 1 of them)
+        pv, pi = torch.topk(scores, k, dim=1)
+        assert torch.equal(cv, pv)
+
+
+@pytest.mark.parametrize("nb", [1, 5])
+def test_graph_replay_gives_the_same_ids_as_eager_launches(setup, nb):
+    """hipGraph replay of the decode iteration (device-side position counters, ping-pong parity pairs) vs eager."""
+    from neuspeech1_amd.generate import Generator
+    g, dims, gen, x, prompt = setup
+    kw = dict(num_beams=nb, max_new_tokens=40, eos_id=630, repetition_penalty=5.0 if nb > 1 else 1.0,
+              no_repeat_ngram_size=2 if nb > 1 else 0)
+    a = Generator(gen.eng, use_graph=False).generate(x, prompt, **kw)
+    b = Generator(gen.eng, use_graph=True, graph_min_steps=0).generate(x, prompt, **kw)
+    c = Generator(gen.eng, use_graph=True, graph_min_steps=0).generate(x, prompt, check_every=1, **kw)
+    assert torch.equal(a, b) and torch.equal(a, c)

@@ -18,7 +18,7 @@ NEW = int(os.environ.get("NEW", 64))
 dev = torch.device("cuda:0")
 dims = WhisperDims(ch=273)
 eng = MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev)
-gen = Generator(eng)
+gen = Generator(eng, use_graph=os.environ.get("GRAPH", "1") == "1")
 x, labels = synth_batch(dims, B, 1234)
 x = torch.from_numpy(x).to(dev)
 prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
