@@ -22,6 +22,8 @@
 namespace {
 
 constexpr int D = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float RESCALE_TH = 8.f;
 
 // ONE LDS image per 64x64 tile serves the row reads (ds_read_b128, lane = row) AND the transposed reads
 // (ds_read_b64_tr_b16): 8-row x 32-column subtiles of 512 B, chunk XOR (row>>2)&3 (cdna guide §5.5 T10 image (a)
@@ -70,7 +72,7 @@ __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 
 
 // =============================================================== forward
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) {
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_attn_desc p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* const Ks = smem;
   char* const Vs = smem + 8192;
@@ -119,38 +121,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const ns_attn_desc p) 
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], st[kt], 0, 0, 0);
       }
     }
-    // mask + running max
+    // Element-wise work is what bounds this kernel at head_dim 64 (32 scores per lane and tile against 16 MFMAs), so
+    // it is kept to max / fma+exp2 / add / cvt per score: masking only on tiles that need it (block-uniform branch),
+    // log2(e) folded into one fma, and the accumulator rescale only when the row maximum moved by more than
+    // RESCALE_TH (the exponent then stays below 2^12, far inside fp16 / fp32 range).
+    const bool need_mask = CAUSAL || (k0 + 64 > p.Lk);
+    if (need_mask) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kt * 32 + crow(r, lh);
+          bool ok = key < p.Lk;
+          if (CAUSAL) ok = ok && (key <= qi + coff);
+          st[kt][r] = ok ? st[kt][r] : -INFINITY;
+        }
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + crow(r, lh);
-        bool ok = key < p.Lk;
-        if (CAUSAL) ok = ok && (key <= qi + coff);
-        const float v = ok ? st[kt][r] : -INFINITY;
-        st[kt][r] = v;
-        mt = fmaxf(mt, v);
-      }
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kt][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);
-    m_run = m_new;
+    const bool moved = mt > m_run + RESCALE_TH;          // also true on the first visible tile (m_run = -inf)
+    if (__builtin_amdgcn_ballot_w64(moved)) {
+      const float m_new = moved ? mt : m_run;
+      const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
+    const float mneg = (m_run == -INFINITY) ? 0.f : -m_run * LOG2E;
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __expf(st[kt][r] - m_use);
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[kt][r], LOG2E, mneg));
         st[kt][r] = e;
         ls += e;
       }
-    l_run = l_run * alpha + ls;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    l_run += ls;
     // O^T += V^T P^T
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -234,11 +248,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
     __syncthreads();
     if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr0, kr1); load_rm(V, p.ldv, k0 + 64, p.Lk, vr0, vr1); }
 
+    // the row constants ride in as the MFMA's initial accumulator: st = S - lse, dp = dP - delta (query on the lane)
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[kt][r] = 0.f; dp[kt][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[kt][r] = -lse; dp[kt][r] = -delta; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 ak = *(const half8*)(Ks + lds_off(kt * 32 + lr, 2 * s + lh));
@@ -247,16 +262,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
         dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, dof[s], dp[kt], 0, 0, 0);
       }
     }
+    if (CAUSAL || k0 + 64 > p.Lk) {      // block-uniform: only tiles that hold invisible keys pay for the mask
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kt * 32 + crow(r, lh);
+          bool ok = key < p.Lk;
+          if (CAUSAL) ok = ok && (key <= qi + coff);
+          st[kt][r] = ok ? st[kt][r] : -INFINITY;
+        }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + crow(r, lh);
-        bool ok = key < p.Lk;
-        if (CAUSAL) ok = ok && (key <= qi + coff);
-        const float pv = ok ? __expf(st[kt][r] - lse) : 0.f;
-        st[kt][r] = pv * (dp[kt][r] - delta);  // dS^T
-      }
+      for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] * LOG2E) * dp[kt][r];   // dS^T
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -332,34 +352,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
     const int q0 = qstart + t * 64;
     __syncthreads();
     store_rm(Qs, qr0, qr1); store_rm(dOs, dr0, dr1);
-    if (threadIdx.x < 64) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
+    // -lse / -delta of the tile's 64 queries; queries past Lq get -inf so their probabilities vanish without a mask
+    if (threadIdx.x < 64) {
+      const bool qok = q0 + (int)threadIdx.x < p.Lq;
+      lse_s[threadIdx.x] = qok ? -lse_r : -INFINITY;
+      del_s[threadIdx.x] = -del_r;
+    }
     __syncthreads();
     if (t + 1 < ntiles) load_all(q0 + 64);
 
+    // the row constants ride in as the initial accumulators (query = accumulator row): st = S - lse, dp = dP - delta
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[qt][r] = 0.f; dp[qt][r] = 0.f; }
+      for (int g = 0; g < 4; ++g) {
+        const float4 nl = *(const float4*)(lse_s + qt * 32 + 8 * g + 4 * lh);
+        const float4 nd = *(const float4*)(del_s + qt * 32 + 8 * g + 4 * lh);
+        st[qt][4 * g + 0] = nl.x; st[qt][4 * g + 1] = nl.y; st[qt][4 * g + 2] = nl.z; st[qt][4 * g + 3] = nl.w;
+        dp[qt][4 * g + 0] = nd.x; dp[qt][4 * g + 1] = nd.y; dp[qt][4 * g + 2] = nd.z; dp[qt][4 * g + 3] = nd.w;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 aq = *(const half8*)(Qs + lds_off(qt * 32 + lr, 2 * s + lh));
         const half8 ad = *(const half8*)(dOs + lds_off(qt * 32 + lr, 2 * s + lh));
-        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, kf[s], st[qt], 0, 0, 0);   // S[q][key]
-        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, vf[s], dp[qt], 0, 0, 0);   // dP[q][key]
+        st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, kf[s], st[qt], 0, 0, 0);   // S[q][key] - lse[q]
+        dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, vf[s], dp[qt], 0, 0, 0);   // dP[q][key] - delta[q]
       }
+    }
+    if (CAUSAL) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = q0 + qt * 32 + crow(r, lh);
+          if (key > qi + coff) st[qt][r] = -INFINITY;
+        }
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ql = qt * 32 + crow(r, lh);
-        const int qi = q0 + ql;
-        bool ok = (qi < p.Lq) && (key < p.Lk);
-        if (CAUSAL) ok = ok && (key <= qi + coff);
-        const float pv = ok ? __expf(st[qt][r] - lse_s[ql]) : 0.f;
-        st[qt][r] = pv;                              // P
-        dp[qt][r] = pv * (dp[qt][r] - del_s[ql]);    // dS
+        const float pv = __builtin_amdgcn_exp2f(st[qt][r] * LOG2E);
+        st[qt][r] = pv;                 // P
+        dp[qt][r] = pv * dp[qt][r];     // dS
       }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
