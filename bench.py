@@ -47,6 +47,17 @@ def cpu_baseline(dims, r, alpha):
             "sample": f"oracle fp32 fwd+bwd, whisper-base {dims.ch}-ch, B={B}, {n} timed passes after 1 warm-up"}
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    need separate profiler runs, so they cannot be collected inside this process): profiles/r1_f_pmc_traffic.json."""
+    try:
+        import json as _j
+        d = _j.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_f_pmc_traffic.json")))
+        return round(d["hbm_bytes_per_launch"]) if kernel and d.get("kernel") == kernel else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +141,7 @@ def main():
         ach = fl / sec / 1e12
         roof = {"bound": "mfma", "kernel": "ns_gemm_p8_kernel" if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                "traffic": _pmc_traffic("ns_gemm_p8_kernel" if dom == "nt256" else None), "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                 "gflop_per_launch": round(fl / n / 1e9, 2),
                 "step_share": {k: {"ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 1),
                                    "launches": v[2]} for k, v in tot.items()}}
