@@ -58,6 +58,33 @@ def _pmc_traffic(kernel):
         return None
 
 
+def eval_tokens_per_s(train_eng, xd, ld, dev):
+    """BASELINE's second metric (eval tokens/sec): whisper-base, 273-ch, B = 128, 64 new tokens with
+    EOS suppressed so every row does identical work; tokens/s = emitted tokens (prompt excluded) / wall time including
+    the encoder pass.  Reported beside the headline metric, never as `value`."""
+    import torch
+    from neuspeech1_amd.engine import MegWhisperEngine
+    from neuspeech1_amd.generate import Generator
+    from neuspeech1_amd.weights import WhisperDims, make_state_dict, synth_batch
+    dims = WhisperDims(ch=273)
+    eng = MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev)
+    gen = Generator(eng)
+    B, NEW = 128, 64
+    x, labels = synth_batch(dims, B, 1234)
+    x = torch.from_numpy(x).to(dev)
+    prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
+    out = {"workload": "whisper-base 273-ch, B=128, prompt 4, 64 new tokens, EOS suppressed, encoder pass included", "unit": "tokens/s"}
+    for name, nb, kw in (("greedy", 1, {}), ("beam5_rep5_ngram2", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
+        for it in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = gen.generate(x, prompt, num_beams=nb, max_new_tokens=NEW, suppress_tokens=[dims.eos_id], check_every=8, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[name] = round(B * (o.shape[1] - 4) / dt, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +95,7 @@ def main():
     ap.add_argument("--lora-r", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the decode (eval tokens/s) leg")
     args = ap.parse_args()
 
     import torch
@@ -149,6 +177,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(dims, args.lora_r, 2.0 * args.lora_r)
 
+    ev = None
+    if rank == 0 and world == 1 and not args.no_eval:
+        ev = eval_tokens_per_s(eng, xd, ld, dev)
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -165,7 +197,7 @@ def main():
                        "algorithmic_gflop_per_sample": gf,
                        "whole_step_mfma_frac": round(value / world * gf * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
                        "final_loss": round(loss_v, 4)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "eval": ev,
         }
         print(json.dumps(out), flush=True)
 
