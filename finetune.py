@@ -113,13 +113,57 @@ def evaluate_loss(model, dataset, collator, batch_size, rank, world, num_workers
     return (t[0] / t[1].clamp_min(1)).item()
 
 
+class DevicePrefetcher:
+    """Host -> device feed of the collated batches on a copy stream, one batch ahead of the step that consumes it
+    (pinned source, so the 319 MB fp32 batch of BASELINE configs[1] moves under the previous step instead of in
+    front of this one).  Yields (input_features, labels) device tensors."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+
+    def _load(self, it):
+        batch = next(it, None)
+        if batch is None:
+            return None
+        if self.stream is None:
+            return batch["input_features"].to(self.device), batch["labels"].to(self.device)
+        with torch.cuda.stream(self.stream):
+            return (batch["input_features"].to(self.device, non_blocking=True),
+                    batch["labels"].to(self.device, non_blocking=True))
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = self._load(it)
+        while nxt is not None:
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+                for t in nxt:
+                    t.record_stream(torch.cuda.current_stream())
+            cur, nxt = nxt, self._load(it)
+            yield cur
+
+
+def grouped(iterable, n):
+    """lists of up to n consecutive items (the last group of an epoch may be shorter, as in HF Trainer)"""
+    buf = []
+    for item in iterable:
+        buf.append(item)
+        if len(buf) == n:
+            yield buf
+            buf = []
+    if buf:
+        yield buf
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print_arguments(args)
-    if args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("gradient_accumulation_steps != 1 is outside the hot path")
-    if args.fine_tune_layers is not None or args.ft_full:
-        raise NotImplementedError("--fine_tune_layers / --ft_full: the engine adapts all encoder layers")
+    if args.gradient_accumulation_steps < 1:
+        raise ValueError("gradient_accumulation_steps must be >= 1")
+    if args.ft_full:
+        raise NotImplementedError("--ft_full (adapters on the decoder too) is outside the hot path: the engine adapts "
+                                  "encoder layers only (all of them, or the first --fine_tune_layers)")
     processor = get_processor(args.base_model, args.language, args.task, args.timestamps, args.local_files_only)
     ds_kw = dict(processor=processor, modal=args.modal, modal_ch=args.eeg_ch, sample_rate=args.sampling_rate,
                  orig_sample_rate=args.orig_sample_rate, language=args.language, filter_dataset=args.filter_dataset,
@@ -172,7 +216,10 @@ def main(argv=None):
             for p in model.model.get_submodule(n).parameters():
                 p.requires_grad = True
     else:
-        prefixes = ["model.encoder"]
+        if args.fine_tune_layers is not None:
+            prefixes = [f"model.encoder.layers.{i}." for i in range(args.fine_tune_layers)]
+        else:
+            prefixes = ["model.encoder"]
         suffixes = ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"]
         target_modules = match_modules_string(model.named_modules(), prefixes, suffixes)
         modules_to_save = ["model.encoder.conv1", "model.encoder.conv2"]
@@ -198,7 +245,8 @@ def main(argv=None):
     output_dir = os.path.join(args.output_dir, os.path.basename(base).replace(":", "_"))
     os.makedirs(output_dir, exist_ok=True)
     B = args.per_device_train_batch_size
-    steps_per_epoch = math.ceil(math.ceil(len(train_dataset) / world) / B)
+    accum = args.gradient_accumulation_steps
+    steps_per_epoch = math.ceil(math.ceil(math.ceil(len(train_dataset) / world) / B) / accum)
     total_steps = steps_per_epoch * args.num_train_epochs
     if args.max_steps > 0:
         total_steps = min(total_steps, args.max_steps)
@@ -218,15 +266,15 @@ def main(argv=None):
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(train_dataset, idx), batch_size=B, shuffle=False,
                                              num_workers=args.num_workers, collate_fn=data_collator, drop_last=False,
                                              pin_memory=True)
-        for batch in loader:
-            x = batch["input_features"].to(whisper.device, non_blocking=True)
-            y = batch["labels"].to(whisper.device, non_blocking=True)
-            if reducer is None:
-                loss = eng.train_step(x, y)
-            else:
-                loss = eng.train_step(x, y, on_ready=reducer.on_ready, reduce_fn=reducer.finish)
+        for group in grouped(DevicePrefetcher(loader, whisper.device), accum):
+            rk = dict(on_ready=reducer.on_ready, reduce_fn=reducer.finish) if reducer is not None else {}
+            if len(group) == 1:
+                loss = eng.train_step(group[0][0], group[0][1], **rk)
+            else:       # gradient accumulation: the exchange and the optimizer run with the last micro-batch
+                micro = [eng.accumulate_step(x, y, mi, len(group), **rk) for mi, (x, y) in enumerate(group)]
+                loss = torch.stack(micro).mean()
             step += 1
-            n_log += x.shape[0]
+            n_log += sum(x.shape[0] for x, _ in group)
             if step % args.logging_steps == 0 and rank == 0:
                 dt = time.time() - t_log
                 rec = {"step": step, "epoch": round(step / steps_per_epoch, 3), "loss": round(loss.item(), 5),

@@ -43,6 +43,7 @@ class LoraSpec:
     dropout: float = 0.05
     adalora: bool = False
     orth_reg_weight: float = 0.5
+    layers: int | None = None     # adapt only encoder layers 0 .. layers-1 (finetune.py --fine_tune_layers, :188-190)
 
     @property
     def scale(self) -> float:
@@ -105,6 +106,9 @@ class MegWhisperEngine:
         self.r = lora.r_pad if lora else 0          # MFMA K granularity: ranks are zero-padded to a multiple of 16
         self.r_real = lora.r if lora else 0
         self.adalora = bool(lora and lora.adalora)
+        self.n_lora = 0 if not lora else (dims.enc_layers if lora.layers is None else int(lora.layers))
+        if lora and not 1 <= self.n_lora <= dims.enc_layers:
+            raise ValueError(f"LoraSpec.layers={lora.layers} outside 1..{dims.enc_layers}")
         # ---------------- frozen operand packs
         e = "model.encoder."
         self.enc_pos = g(e + "embed_positions.weight").contiguous()
@@ -162,7 +166,7 @@ class MegWhisperEngine:
         segs = []  # (name, numel)
         self.lora_names = []
         if self.lora:
-            for i in reversed(range(dims.enc_layers)):
+            for i in reversed(range(self.n_lora)):
                 p = f"model.encoder.layers.{i}."
                 # A of q,k,v contiguous -> one stacked (3r, d) operand
                 segs += [(p + "self_attn.qkv.lora_A", 3 * r * d)]
@@ -209,7 +213,7 @@ class MegWhisperEngine:
                 else:                   # peft LoRA: A kaiming_uniform(a=sqrt(5)), B = 0
                     torch.nn.init.kaiming_uniform_(a_view[:rr], a=math.sqrt(5))
 
-            for i in range(dims.enc_layers):
+            for i in range(self.n_lora):
                 p = f"model.encoder.layers.{i}."
                 A = self.pview(p + "self_attn.qkv.lora_A").view(3, r, d)
                 E3 = self.pview(p + "self_attn.qkv.lora_E").view(3, r) if self.adalora else None
@@ -253,7 +257,7 @@ class MegWhisperEngine:
         if self.lora:
             sc = self.lora.scale
             qs = 64 ** -0.5
-            for i in range(dims.enc_layers):
+            for i in range(self.n_lora):
                 p = f"model.encoder.layers.{i}."
                 o = {"Aqkv": z(3 * r, d), "AqkvT": z(d, 3 * r), "sBqkv": z(3 * d, r),
                      "sBqT": z(r, d), "sBkT": z(r, d), "sBvT": z(r, d)}
@@ -281,7 +285,7 @@ class MegWhisperEngine:
             # orthogonality regulariser over every lora_A (r x in) and lora_B (out x r), live ranks only
             oj, rr = [], self.r_real
             gp = lambda name: self.G.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
-            for i in range(dims.enc_layers):
+            for i in range(self.n_lora):
                 p = f"model.encoder.layers.{i}."
                 for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
                     oj.append((pp(p + "self_attn.qkv.lora_A") + 4 * j * r * d, gp(p + "self_attn.qkv.lora_A") + 4 * j * r * d, rr, d, d, 0))
@@ -453,7 +457,9 @@ class MegWhisperEngine:
                  bias=pb("conv2"), C16=b["pre2"], c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
                  pos_rows=S, flags=NS_GEMM_GELU)
         dp = self._drop_p()
+        rank = r
         for i, Lw in enumerate(self.enc):
+            r = rank if i < self.n_lora else 0     # --fine_tune_layers: only the first n_lora layers carry adapters
             j = i if train else 0
             hin = h[2 * i] if train else h[i % 2 * 0 + (0 if i % 2 == 0 else 1)]
             if train:
@@ -491,6 +497,7 @@ class MegWhisperEngine:
             else:
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j], G16=b["gf"][j], gelu=True)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout)
+        r = rank
         hlast = h[2 * dims.enc_layers] if train else h[0]
         b["h_last"] = hlast
         ops.layernorm_fwd(hlast, *self.enc_ln, b["enc16"], *b["enc_st"], M, d)
@@ -626,7 +633,9 @@ class MegWhisperEngine:
                           b["dh16"], M, d)
         sc = self.lora.scale if r else 0.0
         qs = 64 ** -0.5
+        rank, nl = r, self.n_lora
         for i in reversed(range(dims.enc_layers)):
+            r = rank if i < nl else 0
             Lw = self.enc[i]
             p = f"model.encoder.layers.{i}."
             hin, hmid = h[2 * i], h[2 * i + 1]
@@ -679,11 +688,13 @@ class MegWhisperEngine:
             else:
                 self._dgrad(dqkv, M, Lw["qkv"], b["dx16"])
             ops.layernorm_bwd(b["dx16"], False, hin, *b["st1"][i], Lw["ln1"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
-            if on_ready is not None and r and i in (dims.enc_layers // 2, 0):
-                hi_l = dims.enc_layers - 1 if i == dims.enc_layers // 2 else dims.enc_layers // 2 - 1
+            if on_ready is not None and r and i in (nl // 2, 0):
+                # adapter gradients of layers [i, hi_l] are final: two chunks (upper half, lower half of the adapted layers)
+                hi_l = nl - 1 if (i == nl // 2 and i != 0) or nl // 2 == 0 else nl // 2 - 1
                 lo_off = self.seg_off[f"model.encoder.layers.{hi_l}.self_attn.qkv.lora_A"][0]
                 end = self.lora_end if i == 0 else self.seg_off[f"model.encoder.layers.{i - 1}.self_attn.qkv.lora_A"][0]
                 on_ready(lo_off, end)
+        r = rank
         # ---- conv stem (all three convs are trainable: modules_to_save, finetune.py:202)
         if self.train_convs:
             self._stem_backward(b)
@@ -771,6 +782,32 @@ class MegWhisperEngine:
             reduce_fn()
         self.optimizer_step()
         return loss
+
+    def accumulate_step(self, x32, labels, index: int, count: int, on_ready=None, reduce_fn=None):
+        """One micro-batch of `count` (finetune.py --gradient_accumulation_steps, :56,235; HF Trainer divides each
+        micro-loss by `count`): gradients add up in G, the exchange and the optimizer run with the last one.  Returns
+        the micro-batch loss (a clone: the device scalar is overwritten by the next forward)."""
+        if index == 0:
+            self.zero_grad()
+        seed = self.drop_seed
+        self.drop_seed = seed * count + index            # a different dropout mask per micro-batch
+        loss, _ = self.forward(x32, labels, train=True, compute_grad=True)
+        self.drop_seed = seed
+        last = index == count - 1
+        if last and count > 1:
+            # the earlier micro-batches' gradients are already in G: scale the sum once instead of every loss
+            self.backward(None)
+            self.G.mul_(1.0 / count)
+            if on_ready is not None:
+                on_ready(0, self.n_train)
+        else:
+            self.backward(on_ready if last else None)
+        out = loss.clone()
+        if last:
+            if reduce_fn is not None:
+                reduce_fn()
+            self.optimizer_step()
+        return out
 
     # ------------------------------------------------------------------ export
     def conv_weight(self, name: str) -> torch.Tensor:

@@ -84,10 +84,13 @@ class PeftModel(nn.Module):
     # -- construction
     @staticmethod
     def _inject(model, config: LoraConfig):
-        want = set(_expected_targets(model))
-        if set(config.target_modules) != want:
-            raise NotImplementedError("the HIP engine carries LoRA on ALL encoder q/k/v/out/fc1/fc2 modules "
-                                      f"({len(want)} names); got {len(config.target_modules)} target modules")
+        full = _expected_targets(model)
+        n = len(config.target_modules)
+        # all six Linear modules of the first N encoder layers (N = all: finetune.py:194, N < all: --fine_tune_layers :189-190)
+        if n == 0 or n % len(LORA_SUFFIXES) or set(config.target_modules) != set(full[:n]):
+            raise NotImplementedError("the HIP engine carries adapters on q/k/v/out/fc1/fc2 of the first N encoder layers "
+                                      f"(N = 1..{len(full) // len(LORA_SUFFIXES)}); got {n} target modules that are not such a set "
+                                      "(--ft_full / decoder adapters are outside the hot path)")
         ada = isinstance(config, AdaLoraConfig)
         if not ada and config.r % 16:
             raise NotImplementedError("LoRA rank must be a multiple of 16 (MFMA K granularity)")

@@ -50,6 +50,26 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
     assert 0.0 <= res["teacher_forced_token_accuracy"] <= 1.0
 
 
+def test_finetune_first_layer_only_with_gradient_accumulation(dev, tmp_path):
+    """--fine_tune_layers=1 --gradient_accumulation_steps=2 (finetune.py:56-57,188-190,235): adapters on layer 0 only,
+    one optimizer step per two micro-batches."""
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 16, ch_file=24, name="toyset", seed=2, min_len=120, max_len=520)
+    out = str(tmp_path / "out")
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}",
+                   "--modal=eeg", "--eeg_ch=20", "--sampling_rate=200", "--orig_sample_rate=200", "--timestamps=False",
+                   "--max_audio_len=2.0", "--language=Dutch", "--num_workers=0", "--use_adalora=False", "--fp16=True",
+                   "--num_train_epochs=2", "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4",
+                   "--logging_steps=1", "--eval_steps=100", "--save_steps=100", "--warmup_steps=0", "--learning_rate=1e-3",
+                   "--augment_config_path=None", "--fine_tune_layers=1", "--gradient_accumulation_steps=2"])
+    logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_tiny", "train_log.jsonl"))]
+    assert len(logs) == 4, logs                     # 16 samples / (4 x 2) = 2 optimizer steps per epoch, 2 epochs
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(out, "synthetic_tiny", "checkpoint-final", "adapter_model.safetensors"))
+    assert any(".layers.0." in k and "lora_A" in k for k in sd) and not any(".layers.1." in k and "lora" in k for k in sd)
+
+
 def test_module_api_loss_backward_matches_engine(dev):
     """`.loss.backward()` through the nn.Module surface yields the engine's (unscaled) gradients; merged weights
     reproduce the adapted forward (merge_and_unload, evaluation.py:88-89)."""

@@ -112,8 +112,9 @@ def test_module_names_and_lora_target_selection():
     assert "model.encoder.layers.3.self_attn.k_proj.bias" not in names and "model.decoder.embed_tokens.weight" in names
     assert match_modules([("a.original_module.w", 0), ("b.w", 0)], [""], [""], ["original_module"]) == ["a.original_module.w"]
     from neuspeech1_amd.peft_compat import LoraConfig, get_peft_model
-    with pytest.raises(NotImplementedError):
-        get_peft_model(model, LoraConfig(r=32, lora_alpha=64, target_modules=t[:6]))
+    for bad in (t[:5], t[6:12]):       # not "all six modules of the first N layers" (N = --fine_tune_layers)
+        with pytest.raises(NotImplementedError):
+            get_peft_model(model, LoraConfig(r=32, lora_alpha=64, target_modules=bad))
     pm = get_peft_model(model, LoraConfig(r=32, lora_alpha=64, target_modules=t, lora_dropout=0.05,
                                           modules_to_save=["model.encoder.conv1", "model.encoder.conv2"]))
     for p in pm.parameters():

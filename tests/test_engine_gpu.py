@@ -206,3 +206,57 @@ def test_adalora_forward_backward_vs_oracle(dev):
     l0 = eng.train_step(xd, ld).item()
     l1 = [eng.train_step(xd, ld).item() for _ in range(3)][-1]
     assert l1 < l0 and eng.found_inf_dev.item() == 0
+
+
+def test_fine_tune_layers_adapts_only_the_first_layers(dev):
+    """LoraSpec(layers=1) (finetune.py --fine_tune_layers=1): layer 0 carries adapters, layer 1 runs plain; loss and
+    layer-0 adapter gradients against the oracle given the same (partial) adapter dict."""
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    from oracle import whisper_meg_oracle as O
+    dims, r = TINY, 32
+    sd = make_state_dict(dims, 42)
+    lora_sd = {k: v for k, v in make_lora_state(dims, r, b_std=0.3).items() if ".layers.0." in k}
+    eng = MegWhisperEngine(dims, sd, lora=LoraSpec(r=r, alpha=64.0, dropout=0.0, layers=1), lora_sd=lora_sd,
+                           train_cfg=TrainCfg(), device=dev)
+    assert not any(".layers.1." in n and "lora" in n for n in eng.seg_off)
+    x, labels = synth_batch(dims, 3, 21)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, 2.0)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item())
+    s = eng.loss_scale_dev.item()
+    p = "model.encoder.layers.0."
+    assert rel(eng.gview(p + "fc2.lora_B").view(dims.d, r).cpu() / s, og[p + "fc2.lora_B.weight"]) < 3e-2
+    assert rel(eng.gview(p + "self_attn.out_proj.lora_A").view(r, dims.d).cpu() / s, og[p + "self_attn.out_proj.lora_A.weight"]) < 3e-2
+    assert rel(eng.conv_weight_grad("conv2").float().cpu() / s, og["model.encoder.conv2.weight"]) < 3e-2
+
+
+def test_gradient_accumulation_equals_one_big_batch(dev):
+    """two micro-batches of 2 through accumulate_step == the gradients of the concatenated batch of 4 (dropout off,
+    same number of label tokens per micro-batch so that the mean of means is the mean)."""
+    dims = TINY
+    eng, sd, lora_sd = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    x, labels = synth_batch(dims, 4, 5, min_k=12, max_k=12)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    g_big = eng.G.clone()
+    p0 = eng.P.clone()
+    l0 = eng.accumulate_step(xd[:2], ld[:2], 0, 2)
+    g_half = eng.G.clone()
+    assert eng.step_dev.item() == 0 and torch.equal(eng.P, p0)           # no optimizer step yet
+    # second micro-batch: stop before the optimizer by replaying its pieces
+    seed = eng.drop_seed
+    eng.forward(xd[2:], ld[2:], train=True, compute_grad=True)
+    eng.backward()
+    g_acc = eng.G * 0.5
+    assert rel(g_acc, g_big) < 2e-2, rel(g_acc, g_big)
+    assert g_half.abs().sum() > 0 and l0.item() > 0
+    # and the real thing steps the optimizer exactly once
+    eng.zero_grad()
+    eng.accumulate_step(xd[:2], ld[:2], 0, 2)
+    eng.accumulate_step(xd[2:], ld[2:], 1, 2)
+    assert eng.step_dev.item() == 1 and not torch.equal(eng.P, p0)

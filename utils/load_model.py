@@ -235,7 +235,8 @@ class WhisperForConditionalGeneration(nn.Module):
             pc = self._peft
             ada = getattr(pc, "peft_type", "LORA") == "ADALORA"
             lora = LoraSpec(r=pc.init_r if ada else pc.r, alpha=float(pc.lora_alpha), dropout=float(pc.lora_dropout),
-                            adalora=ada, orth_reg_weight=float(getattr(pc, "orth_reg_weight", 0.0)) if ada else 0.0)
+                            adalora=ada, orth_reg_weight=float(getattr(pc, "orth_reg_weight", 0.0)) if ada else 0.0,
+                            layers=len(pc.target_modules) // 6)
             lora_sd = {}
             for k, v in sd.items():
                 if ".lora_" in k:
@@ -263,7 +264,7 @@ class WhisperForConditionalGeneration(nn.Module):
         d, f, rp, r = eng.dims.d, eng.dims.ffn, eng.r, eng.r_real
         ada = eng.adalora
         W = (lambda m, t: getattr(m, t)["default"]) if ada else (lambda m, t: getattr(m, t)["default"].weight)
-        for i, layer in enumerate(self.model.encoder.layers):
+        for i, layer in enumerate(self.model.encoder.layers[:eng.n_lora]):
             p = f"model.encoder.layers.{i}."
             A = getv(p + "self_attn.qkv.lora_A").view(3, rp, d)
             E = getv(p + "self_attn.qkv.lora_E").view(3, rp) if ada else None
