@@ -57,7 +57,10 @@ enum {
   NS_GEMM_DGELU = 2,     /* C16 = round16(round16(acc) * gelu'(P16)) */
   NS_GEMM_TN = 4,        /* operands are reduction-major: A is (Kred x M) as X[m_red][m], see ns_gemm */
   NS_GEMM_ATOMIC32 = 8,  /* C32 += acc (fp32 atomics), for split reductions */
-  NS_GEMM_DROP_A = 16    /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection) */
+  NS_GEMM_DROP_A = 16,   /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection) */
+  NS_GEMM_GELU_SAVE_GRAD = 32, /* with NS_GEMM_GELU: C16 = round16(gelu'(x)) instead of x = round16(acc+bias): the backward then
+                                  multiplies (NS_GEMM_MUL_P16) instead of re-evaluating erf / exp per element */
+  NS_GEMM_MUL_P16 = 64   /* C16 = round16(round16(acc) * P16) */
 };
 
 /*
@@ -146,10 +149,11 @@ int ns_embed_pos(const int64_t* ids, const float* E32, const float* P32, float* 
                  int pos0, const int* pos0_dev, void* stream);
 
 /* conv-stem backward seams (the GELUs at utils/model_utils.py:14 and
- * utils/load_model.py:410-411): out16[map(row)] = round16(a16[row] * gelu'(pre16[row]));
+ * utils/load_model.py:410-411): out16[map(row)] = round16(a16[row] * gelu'(pre16[row])), or, with pre_is_grad,
+ * round16(a16[row] * pre16[row]) (pre16 already holds gelu', see NS_GEMM_GELU_SAVE_GRAD);
  * bias gradient out32[c] += alpha * sum_rows a16[row][c] (fp32 atomics). */
 int ns_dgelu_mul(const void* a16, const void* pre16, void* out16, const ns_rowmap* out_map, int rows, int cols,
-                 void* stream);
+                 int pre_is_grad, void* stream);
 int ns_colsum(const void* a16, float* out32, int rows, int cols, int ld, float alpha, void* stream);
 
 /* batched fp32 -> fp16 operand refresh after an optimizer step:

@@ -51,6 +51,12 @@ __device__ __forceinline__ float ns_gelu(float x) {
   ns_gelu_terms(x, cdf, pdf);
   return x * cdf;
 }
+__device__ __forceinline__ void ns_gelu_both(float x, float& g, float& dg) {
+  float cdf, pdf;
+  ns_gelu_terms(x, cdf, pdf);
+  g = x * cdf;
+  dg = cdf + x * pdf;
+}
 __device__ __forceinline__ float ns_gelu_grad(float x) {
   float cdf, pdf;
   ns_gelu_terms(x, cdf, pdf);

@@ -20,7 +20,7 @@
 //       8-B vector along the row: bias, gelu, gelu', fp32 residual (+pos).
 //   TN: fp32 atomics straight from the accumulator layout (lanes 0-31 = 128
 //       contiguous bytes of one row: the full-rate atomic shape).
-#include "ns_common.h"
+#include "ns_gemm_epi.h"
 
 namespace {
 
@@ -340,63 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
       }
   __syncthreads();
 
-  constexpr int TPR = BN == 128 ? 16 : 8;      // threads per tile row
-  constexpr int GPT = BN == 128 ? 2 : 1;       // 4-column groups per thread (second one 64 columns on)
-  constexpr int RPP = NTHREADS / TPR;          // rows per pass
-  const int cg = tid % TPR, r0 = tid / TPR;
-  half_t* const C16 = (half_t*)p.C16;
-  half_t* const G16 = (half_t*)p.G16;
-  const half_t* const P16 = (const half_t*)p.P16;
-  const bool do_gelu = p.flags & NS_GEMM_GELU;
-  const bool do_dgelu = p.flags & NS_GEMM_DGELU;
-
-  float4 bias4[GPT];
-  bool colok[GPT];
-#pragma unroll
-  for (int g = 0; g < GPT; ++g) {
-    const int col = n0 + cg * 4 + g * 64;
-    colok[g] = col + 4 <= p.N;
-    bias4[g] = (p.bias && colok[g]) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int rl = r0; rl < BM; rl += RPP) {
-    const int row = m0 + rl;
-    if (row >= p.M) break;
-    const long long oc = C16 ? rm_off64(p.c16m, row) : 0;
-    const long long og = G16 ? rm_off64(p.g16m, row) : 0;
-    const long long op = P16 ? rm_off64(p.p16m, row) : 0;
-    const long long oh = p.H32 ? rm_off64(p.h32m, row) : 0;
-    const long long opos = p.pos ? (long long)(row % p.pos_rows) * p.N : 0;
-#pragma unroll
-    for (int g = 0; g < GPT; ++g) {
-      if (!colok[g]) continue;
-      const int cl = cg * 4 + g * 64, col = n0 + cl;
-      const float4 a = *(const float4*)(ct + rl * BN + cl);
-      float v[4] = {a.x * alpha + bias4[g].x, a.y * alpha + bias4[g].y, a.z * alpha + bias4[g].z, a.w * alpha + bias4[g].w};
-      if (p.C32) *(float4*)(p.C32 + (long long)row * p.ldc32 + col) = make_float4(v[0], v[1], v[2], v[3]);
-      half4 v16 = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      if (do_dgelu) {
-        const half4 pv = *(const half4*)(P16 + op + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v16[e] = (half_t)((float)v16[e] * ns_gelu_grad((float)pv[e]));
-      }
-      if (C16) *(half4*)(C16 + oc + col) = v16;
-      half4 gv = v16;
-      if (do_gelu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gv[e] = (half_t)ns_gelu((float)v16[e]);
-      }
-      if (G16) *(half4*)(G16 + og + col) = gv;
-      if (p.H32) {
-        float4 h = p.R32 ? *(const float4*)(p.R32 + oh + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        h.x += (float)gv[0]; h.y += (float)gv[1]; h.z += (float)gv[2]; h.w += (float)gv[3];
-        if (p.pos) {
-          const float4 ps = *(const float4*)(p.pos + opos + col);
-          h.x += ps.x; h.y += ps.y; h.z += ps.z; h.w += ps.w;
-        }
-        *(float4*)(p.H32 + oh + col) = h;
-      }
-    }
-  }
+  ns_nt_epilogue<BM, BN, NTHREADS>(p, ct, m0, n0, tid);    // shared: loads batched ahead of the stores, settled once
 }
 
 template <bool TN, int BN, bool DROP>
@@ -450,7 +394,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     NS_CHECK_ARG(d->K2 == 0, "ns_gemm(TN): second product unsupported");
     NS_CHECK_ARG(d->splits >= 1 && d->splits <= 65535, "ns_gemm(TN): bad splits=%d", d->splits);
   }
-  if (d->flags & NS_GEMM_DGELU) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU needs P16");
+  if (d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU / MUL_P16 need P16");
+  NS_CHECK_ARG(!(d->flags & NS_GEMM_GELU_SAVE_GRAD) || (d->flags & NS_GEMM_GELU), "ns_gemm: GELU_SAVE_GRAD needs GELU");
   NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "ns_gemm: drop_p out of range");
 
   // skinny-N tiles (128x32) also serve small-M decode GEMMs: 4x more workgroups than 128x128 tiles when M <= 1024

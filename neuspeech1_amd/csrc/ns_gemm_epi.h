@@ -24,7 +24,7 @@ __device__ __forceinline__ long long ns_rm_off64(const ns_rowmap& m, int row) {
 enum { NS_EPI_PLAIN = 0, NS_EPI_RES = 1, NS_EPI_DGELU = 2 };
 
 __device__ __forceinline__ int ns_epi_kind(const ns_gemm_desc& p) {
-  return p.H32 ? NS_EPI_RES : ((p.flags & NS_GEMM_DGELU) ? NS_EPI_DGELU : NS_EPI_PLAIN);
+  return p.H32 ? NS_EPI_RES : ((p.flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) ? NS_EPI_DGELU : NS_EPI_PLAIN);
 }
 
 template <int BM_, int BN_, int NTHREADS_>
@@ -97,6 +97,7 @@ __device__ __forceinline__ void ns_epi_finish(const ns_gemm_desc& p, const float
   half_t* const C16 = (half_t*)p.C16;
   half_t* const G16 = (half_t*)p.G16;
   const bool do_gelu = p.flags & NS_GEMM_GELU;
+  const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
   const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
 
   float4 bias4[G::GPT];
@@ -149,15 +150,25 @@ __device__ __forceinline__ void ns_epi_finish(const ns_gemm_desc& p, const float
       half4 v16 = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       if (KIND == NS_EPI_DGELU) {
         const half4 pv = rs.pre[i][g];
+        if (mulp) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v16[e] = (half_t)((float)v16[e] * ns_gelu_grad((float)pv[e]));
+          for (int e = 0; e < 4; ++e) v16[e] = (half_t)((float)v16[e] * (float)pv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v16[e] = (half_t)((float)v16[e] * ns_gelu_grad((float)pv[e]));
+        }
       }
-      if (C16) *(half4*)(C16 + oc + col) = v16;
-      half4 gv = v16;
+      half4 gv = v16, cv = v16;
       if (do_gelu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gv[e] = (half_t)ns_gelu((float)v16[e]);
+        for (int e = 0; e < 4; ++e) {
+          float g_, dg_;
+          ns_gelu_both((float)v16[e], g_, dg_);
+          gv[e] = (half_t)g_;
+          if (save_grad) cv[e] = (half_t)dg_;
+        }
       }
+      if (C16) *(half4*)(C16 + oc + col) = cv;
       if (G16) *(half4*)(G16 + og + col) = gv;
       if (KIND == NS_EPI_RES) {
         float4 h = rs.res[i][g];

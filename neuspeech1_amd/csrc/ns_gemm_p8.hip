@@ -230,7 +230,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
   NS_STAMP(1);
   stage(0, RA0, 0); stage(0, RB0, 0); stage(0, RB1, 0); stage(0, RA1, 0);
   stage(1, RA0, 1); stage(1, RB0, 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // only RA0 / RB0 of tile 0 (the first four pieces) must have landed: phase 1 reads nothing else, and the in-loop
+  // vmcnt(8) of phases 1 and 2 retires RB1 / RA1 one phase before they are read
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   NS_P8_BARRIER();
   NS_STAMP(2);
   if (wm == 1) NS_P8_BARRIER();     // group 1 runs one barrier interval behind group 0
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     half_t* const G16 = (half_t*)p.G16;
     const half_t* const P16 = (const half_t*)p.P16;
     const bool do_gelu = p.flags & NS_GEMM_GELU;
+    const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
     f32x4 res[KIND == NS_EPI_RES ? 16 : 1][2];
     half8 pre[KIND == NS_EPI_DGELU ? 16 : 1];
     auto prefetch = [&](int i0) __attribute__((always_inline)) {
@@ -326,15 +329,25 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
         if (row >= p.M) continue;
         half8 v = *(const half8*)(hs + rl * LDH + ecg * 16);
         if (KIND == NS_EPI_DGELU) {
+          if (mulp) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * ns_gelu_grad((float)pre[i][e]));
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * (float)pre[i][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * ns_gelu_grad((float)pre[i][e]));
+          }
         }
-        if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = v;
-        half8 gv = v;
+        half8 gv = v, cv = v;
         if (do_gelu) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) gv[e] = (half_t)ns_gelu((float)v[e]);
+          for (int e = 0; e < 8; ++e) {
+            float g_, dg_;
+            ns_gelu_both((float)v[e], g_, dg_);
+            gv[e] = (half_t)g_;
+            if (save_grad) cv[e] = (half_t)dg_;
+          }
         }
+        if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = cv;
         if (G16) *(half8*)(G16 + ns_rm_off64(p.g16m, row) + ecol) = gv;
         if (KIND == NS_EPI_RES) {
           f32x4 h0 = res[i][0], h1 = res[i][1];

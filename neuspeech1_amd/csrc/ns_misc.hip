@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void cast_jobs_kernel(const ns_cast_job* __res
 
 // out16[map(row)][c] = round16(a16[row][c] * gelu'(pre16[row][c]))   (conv-stem backward seam)
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const half_t* __restrict__ a, const half_t* __restrict__ pre,
-                                                         half_t* __restrict__ out, ns_rowmap om, int rows, int cols) {
+                                                         half_t* __restrict__ out, ns_rowmap om, int rows, int cols,
+                                                         int pre_is_grad) {
   const int cpr = cols / 8;
   const long long total = (long long)rows * cpr;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const half_t* __restrict
     const half8 pv = *(const half8*)(pre + (long long)row * cols + c);
     half8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)av[e] * ns_gelu_grad((float)pv[e]));
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)av[e] * (pre_is_grad ? (float)pv[e] : ns_gelu_grad((float)pv[e])));
     long long off;
     if (om.seg_rows > 0) { const int sg = row / om.seg_rows; off = (long long)sg * om.seg_stride + (long long)(row - sg * om.seg_rows) * om.ld; }
     else off = (long long)row * om.ld;
@@ -230,14 +231,14 @@ extern "C" int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream
 }
 
 extern "C" int ns_dgelu_mul(const void* a16, const void* pre16, void* out16, const ns_rowmap* out_map, int rows, int cols,
-                            void* stream) {
+                            int pre_is_grad, void* stream) {
   NS_CHECK_ARG(a16 && pre16 && out16 && out_map && rows > 0 && cols > 0 && cols % 8 == 0 && out_map->ld % 8 == 0,
                "ns_dgelu_mul: bad arguments");
   long long total = (long long)rows * (cols / 8);
   int nb = (int)((total + 255) / 256);
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(dgelu_mul_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)a16,
-                     (const half_t*)pre16, (half_t*)out16, *out_map, rows, cols);
+                     (const half_t*)pre16, (half_t*)out16, *out_map, rows, cols, pre_is_grad);
   NS_CHECK_LAUNCH("ns_dgelu_mul");
   return NS_OK;
 }

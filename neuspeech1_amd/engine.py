@@ -28,7 +28,12 @@ import torch
 
 from . import ops
 from .lib import AdamWCfg
-from .ops import NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_TN, rowmap
+from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN,
+                  rowmap)
+
+# Every GELU site saves gelu'(x) (fp16) where the reference keeps x for autograd: the backward seams then multiply
+# (NS_GEMM_MUL_P16 / ns_dgelu_mul(pre_is_grad)) instead of re-evaluating erf / exp for every element.
+GELU_FWD = NS_GEMM_GELU | NS_GEMM_GELU_SAVE_GRAD
 from .weights import LORA_SUFFIXES, WhisperDims
 
 F16, F32 = torch.float16, torch.float32
@@ -407,7 +412,7 @@ class MegWhisperEngine:
                  C16=C16, c16m=rowmap(ldc or lin.N) if C16 is not None else None,
                  G16=G16, g16m=rowmap(lin.N) if G16 is not None else None,
                  R32=R32, H32=H32, h32m=rowmap(lin.N) if H32 is not None else None,
-                 flags=NS_GEMM_GELU if gelu else 0)
+                 flags=GELU_FWD if gelu else 0)
 
     def _dgrad(self, dy16, M, lin: _Lin, out16, *, ldy=None, P16=None, A2=None, lda2=0, K2=0, B2=None,
                R32=None, H32=None, drop=False):
@@ -417,7 +422,7 @@ class MegWhisperEngine:
                  C16=out16, c16m=rowmap(lin.K) if out16 is not None else None,
                  P16=P16, p16m=rowmap(lin.K) if P16 is not None else None,
                  R32=R32, H32=H32, h32m=rowmap(lin.K) if H32 is not None else None,
-                 flags=NS_GEMM_DGELU if P16 is not None else 0,
+                 flags=NS_GEMM_MUL_P16 if P16 is not None else 0,
                  drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
 
     def _drop_p(self):
@@ -444,18 +449,18 @@ class MegWhisperEngine:
         pb = lambda n: self.pview(f"model.encoder.{n}.bias")  # noqa: E731
         # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
         ops.gemm(A=b["xin"], am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
-                 bias=pb("conv1.0"), C16=b["pre0"], c16m=rowmap(d), G16=(b["g0"], d), g16m=rowmap(d, T, (T + 2) * d),
-                 flags=NS_GEMM_GELU)
+                 bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d), g16m=rowmap(d, T, (T + 2) * d),
+                 flags=GELU_FWD)
         # conv1.2 (k3,s2) + the encoder's outer GELU
         T2 = T // 2
         ops.gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
-                 bias=pb("conv1.2"), C16=b["pre1"], c16m=rowmap(d), G16=(b["g1"], d),
-                 g16m=rowmap(d, T2, (T2 + 2) * d), flags=NS_GEMM_GELU)
+                 bias=pb("conv1.2"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
+                 g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
         # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
         h = b["h"]
         ops.gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
-                 bias=pb("conv2"), C16=b["pre2"], c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
-                 pos_rows=S, flags=NS_GEMM_GELU)
+                 bias=pb("conv2"), C16=b["pre2"] if train else None, c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
+                 pos_rows=S, flags=GELU_FWD)
         dp = self._drop_p()
         rank = r
         for i, Lw in enumerate(self.enc):
@@ -489,13 +494,13 @@ class MegWhisperEngine:
             if r:
                 ops.gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 2)
-                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j], G16=b["gf"][j], gelu=True, A2=b["u1"][j], lda2=r,
+                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True, A2=b["u1"][j], lda2=r,
                           K2=r, B2=lo["fc1_sB"])
                 ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 3)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
             else:
-                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j], G16=b["gf"][j], gelu=True)
+                self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout)
         r = rank
         hlast = h[2 * dims.enc_layers] if train else h[0]
@@ -731,7 +736,7 @@ class MegWhisperEngine:
         c0, c1, c2 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"], self.conv_ops["conv2"]
         gp = lambda name: self.G.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
         # d(pre2) = round16(dh) * gelu'(pre2), halo layout (B, S+2, d)
-        ops.dgelu_mul(b["dh16"], b["pre2"], (b["dpre2"], d), rowmap(d, S, (S + 2) * d), M, d)
+        ops.dgelu_mul(b["dh16"], b["pre2"], (b["dpre2"], d), rowmap(d, S, (S + 2) * d), M, d, pre_is_grad=True)
         dp2 = (b["dpre2"], d)
         hal2 = rowmap(d, S, (S + 2) * d)
         ops.colsum(b["dpre2"], gp("model.encoder.conv2.bias"), B * (S + 2), d, d)
@@ -741,9 +746,9 @@ class MegWhisperEngine:
         ev = rowmap(2 * d, S, T2 * d)
         evh = rowmap(2 * d, S, (T2 + 2) * d)
         ops.gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=(b["dpre1"], d), c16m=evh, P16=b["pre1"],
-                 p16m=ev, flags=NS_GEMM_DGELU)
+                 p16m=ev, flags=NS_GEMM_MUL_P16)
         ops.gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dpre1"], 2 * d), c16m=evh,
-                 P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_DGELU)
+                 P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         dp1 = (b["dpre1"], d)
         hal1 = rowmap(d, T2, (T2 + 2) * d)
         ops.colsum(b["dpre1"], gp("model.encoder.conv1.2.bias"), B * (T2 + 2), d, d)
@@ -751,9 +756,9 @@ class MegWhisperEngine:
                     bm=rowmap(2 * d, T2, (T + 2) * d))
         ev = rowmap(2 * d, T2, T * d)
         ops.gemm(A=dp1, am=hal1, K=d, B=c1["we"], ldb=d, M=B * T2, N=d, C16=b["dpre0"], c16m=ev, P16=b["pre0"], p16m=ev,
-                 flags=NS_GEMM_DGELU)
+                 flags=NS_GEMM_MUL_P16)
         ops.gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
-                 P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_DGELU)
+                 P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         ops.colsum(b["dpre0"], gp("model.encoder.conv1.0.bias"), B * T, d, d)
         self._wgrad(b["dpre0"], 0, b["xin"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
                     bm=rowmap(Cp, T, (T + 2) * Cp))

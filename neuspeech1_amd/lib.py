@@ -117,6 +117,7 @@ class BeamDesc(C.Structure):
 
 
 NS_GEMM_GELU, NS_GEMM_DGELU, NS_GEMM_TN, NS_GEMM_ATOMIC32, NS_GEMM_DROP_A = 1, 2, 4, 8, 16
+NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16 = 32, 64
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -131,7 +132,7 @@ SIGNATURES = {
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ns_embed_pos": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _vp]),
+    "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _i, _vp]),
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -8,11 +8,12 @@ import torch
 
 from . import lib as L
 from .lib import (AdamWCfg, AttnDesc, CastJob, GemmDesc, RowMap, NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A,
-                  NS_GEMM_GELU, NS_GEMM_TN)
+                  NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN)
 
 __all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pack", "embed_pos", "attn_fwd",
            "attn_bwd", "cross_entropy", "dgelu_mul", "colsum", "argmax_rows", "grad_norm", "adamw_step", "cast_jobs", "make_cast_jobs",
-           "NS_GEMM_GELU", "NS_GEMM_DGELU", "NS_GEMM_TN", "NS_GEMM_ATOMIC32", "NS_GEMM_DROP_A"]
+           "NS_GEMM_GELU", "NS_GEMM_DGELU", "NS_GEMM_TN", "NS_GEMM_ATOMIC32", "NS_GEMM_DROP_A", "NS_GEMM_GELU_SAVE_GRAD",
+           "NS_GEMM_MUL_P16"]
 
 
 def _stream() -> int:
@@ -93,8 +94,8 @@ def embed_pos(ids, E32, P32, h32, rows, Lseq, d, pos0=0, pos0_dev=None):
                                   _stream()), "ns_embed_pos")
 
 
-def dgelu_mul(a16, pre16, out16, out_map, rows, cols):
-    L.check(L.load().ns_dgelu_mul(ptr(a16), ptr(pre16), ptr(out16), C.byref(out_map), rows, cols, _stream()),
+def dgelu_mul(a16, pre16, out16, out_map, rows, cols, pre_is_grad=False):
+    L.check(L.load().ns_dgelu_mul(ptr(a16), ptr(pre16), ptr(out16), C.byref(out_map), rows, cols, int(pre_is_grad), _stream()),
             "ns_dgelu_mul")
 
 

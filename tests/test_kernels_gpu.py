@@ -81,6 +81,20 @@ def test_gemm_epilogues(ops, dev):
     x = P.float().requires_grad_(True)
     F.gelu(x).backward((A.float() @ B.float().T).half().float())
     close(D, x.grad, 4e-3, 3e-3, "dgelu")
+    # gelu with the derivative saved in place of the pre-activation, then the multiply-only backward seam
+    Dg = torch.empty_like(C16)
+    G2 = torch.empty_like(C16)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=Dg, c16m=ops.rowmap(N), G16=G2,
+             g16m=ops.rowmap(N), flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD)
+    xg = C16.float().requires_grad_(True)
+    F.gelu(xg).sum().backward()
+    close(Dg, xg.grad, 1e-3, 1e-3, "saved gelu'")
+    assert torch.equal(G2, G16)
+    D2 = torch.empty_like(C16)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D2, c16m=ops.rowmap(N), P16=Dg, p16m=ops.rowmap(N),
+             flags=ops.NS_GEMM_MUL_P16)
+    assert torch.equal(D2, ((A.float() @ B.float().T).half().float() * Dg.float()).half()) or \
+        (D2.float() - (A.float() @ B.float().T).half().float() * Dg.float()).abs().max() < 4e-3
 
 
 def test_gemm_second_product_groups(ops, dev):
@@ -212,6 +226,9 @@ def test_embed_cast_dgelu_colsum(ops, dev):
     rows, cols, seg = 128, 64, 64
     a, pre = rnd((rows, cols), dev, 1.0, seed=4), rnd((rows, cols), dev, 1.0, seed=5)
     out = torch.zeros(2, seg + 2, cols, device=dev, dtype=torch.float16)
+    out_m = torch.zeros(2, seg + 2, cols, device=dev, dtype=torch.float16)
+    ops.dgelu_mul(a, pre, (out_m, cols), ops.rowmap(cols, seg, (seg + 2) * cols), rows, cols, pre_is_grad=True)
+    assert torch.equal(out_m[:, 1:seg + 1].reshape(rows, cols), (a.float() * pre.float()).half())
     ops.dgelu_mul(a, pre, (out, cols), ops.rowmap(cols, seg, (seg + 2) * cols), rows, cols)
     x = pre.float().requires_grad_(True)
     F.gelu(x).backward(a.float())
