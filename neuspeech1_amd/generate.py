@@ -95,8 +95,15 @@ class Generator:
                 eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
                 ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["cq"], C16=qc)
-                ops.attn_decode(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, groups=B, nq=nb, H=H, Lk=S, Lk_max=S, ldq=d,
-                                ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
+                if nb > 1:
+                    # beams of a sequence = the "queries" of one flash-attention problem over the sequence's encoder
+                    # K/V: the MFMA kernel reads the 384 KB per (sequence, head) once and is HBM-bound (~60 us / layer
+                    # at B = 128), where the per-key VALU dot products of ns_attn_decode took 108 us at 5 beams
+                    ops.attn_fwd(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, B=B, H=H, Lq=nb, Lk=S, ldq=d, ldk=2 * d,
+                                 ldv=2 * d, ldo=d, causal=False)
+                else:
+                    ops.attn_decode(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, groups=B, nq=nb, H=H, Lk=S, Lk_max=S, ldq=d,
+                                    ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
                 eng._lin(ao, Bp, Lw["cout"], R32=h[1], H32=h[0])
                 ops.layernorm_fwd(h[0], *Lw["ln3"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["fc1"], C16=pre, G16=gf, gelu=True)
