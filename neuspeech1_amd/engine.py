@@ -111,6 +111,9 @@ class MegWhisperEngine:
         self.r = lora.r_pad if lora else 0          # MFMA K granularity: ranks are zero-padded to a multiple of 16
         self.r_real = lora.r if lora else 0
         self.adalora = bool(lora and lora.adalora)
+        # front-end variant (utils/model_utils.py:9-23): 'base' = conv1.0 (k3,s1) + GELU + conv1.2 (k3,s2); 'replace' =
+        # ONE stride-2 conv `encoder.conv1` straight from the MEG channels
+        self.frontend = "replace" if ("model.encoder.conv1.weight" in sd and "model.encoder.conv1.0.weight" not in sd) else "base"
         self.n_lora = 0 if not lora else (dims.enc_layers if lora.layers is None else int(lora.layers))
         if lora and not 1 <= self.n_lora <= dims.enc_layers:
             raise ValueError(f"LoraSpec.layers={lora.layers} outside 1..{dims.enc_layers}")
@@ -164,6 +167,13 @@ class MegWhisperEngine:
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
+    def _conv_list(self):
+        """(name, in channels, padded in channels) of the trainable convs, in backward-completion order"""
+        d = self.dims.d
+        if self.frontend == "base":
+            return (("conv2", d, d), ("conv1.2", d, d), ("conv1.0", self.dims.ch, self.dims.ch_pad))
+        return (("conv2", d, d), ("conv1", self.dims.ch, self.dims.ch_pad))
+
     def _build_trainables(self, sd, lora_sd):
         """One flat fp32 buffer, ordered by backward completion: LoRA of the top encoder layer first, conv stem last."""
         dims, d, f, r = self.dims, self.dims.d, self.dims.ffn, self.r
@@ -183,9 +193,12 @@ class MegWhisperEngine:
                 if self.adalora:
                     segs += [(p + "self_attn.qkv.lora_E", 3 * r), (p + "self_attn.out_proj.lora_E", r),
                              (p + "fc1.lora_E", r), (p + "fc2.lora_E", r)]
-        segs += [("model.encoder.conv2.wp", d * 3 * d), ("model.encoder.conv2.bias", d),
-                 ("model.encoder.conv1.2.wp", d * 3 * d), ("model.encoder.conv1.2.bias", d),
-                 ("model.encoder.conv1.0.wp", d * 3 * Cp), ("model.encoder.conv1.0.bias", d)]
+        segs += [("model.encoder.conv2.wp", d * 3 * d), ("model.encoder.conv2.bias", d)]
+        if self.frontend == "base":
+            segs += [("model.encoder.conv1.2.wp", d * 3 * d), ("model.encoder.conv1.2.bias", d),
+                     ("model.encoder.conv1.0.wp", d * 3 * Cp), ("model.encoder.conv1.0.bias", d)]
+        else:
+            segs += [("model.encoder.conv1.wp", d * 3 * Cp), ("model.encoder.conv1.bias", d)]
         self.seg_off = {}
         off = 0
         for nm, n in segs:
@@ -197,7 +210,7 @@ class MegWhisperEngine:
         self.lora_end = self.seg_off["model.encoder.conv2.wp"][0]
         g = self._sd_get
         # conv masters in packed GEMM layout (N, 3, Cp): wp[n, k, c] = w[n, c, k]
-        for nm, cin, cp in (("conv2", d, d), ("conv1.2", d, d), ("conv1.0", dims.ch, Cp)):
+        for nm, cin, cp in self._conv_list():
             w = g(f"model.encoder.{nm}.weight")
             wp = self.pview(f"model.encoder.{nm}.wp").view(d, 3, cp)
             wp[:, :, :cin] = w.permute(0, 2, 1)
@@ -247,11 +260,11 @@ class MegWhisperEngine:
         P = self.P
         pp = lambda name: P.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
         self.conv_ops = {}
-        for nm, cp in (("conv2", d), ("conv1.2", d), ("conv1.0", Cp)):
+        for nm, _, cp in self._conv_list():
             key = f"model.encoder.{nm}"
             o = {"w": z(d, 3 * cp), "cp": cp}
             jobs.append((pp(key + ".wp"), o["w"].data_ptr(), d, 3 * cp, 3 * cp, 3 * cp, 1.0, 0))
-            if nm != "conv1.0":  # stride-2 dgrad operands: even rows use tap 1, odd rows taps (2 | 0)
+            if nm in ("conv2", "conv1.2"):  # stride-2 dgrad operands: even rows use tap 1, odd rows taps (2 | 0)
                 o["we"] = z(cp, d)
                 o["wo"] = z(cp, 2 * d)
                 jobs.append((pp(key + ".wp") + 4 * cp, o["we"].data_ptr(), d, cp, 3 * cp, d, 1.0, 1))
@@ -333,8 +346,9 @@ class MegWhisperEngine:
         f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
         b = {"B": B, "L": L}
         b["xin"] = h16(B, T + 2, Cp)
-        b["pre0"] = h16(B * T, d)
-        b["g0"] = h16(B, T + 2, d)
+        if self.frontend == "base":
+            b["pre0"] = h16(B * T, d)
+            b["g0"] = h16(B, T + 2, d)
         b["pre1"] = h16(B * T // 2, d)
         b["g1"] = h16(B, T // 2 + 2, d)
         b["pre2"] = h16(M, d)
@@ -432,7 +446,10 @@ class MegWhisperEngine:
                am=None, bm=None):
         gptr = self.G.data_ptr() + 4 * (self.seg_off[gname][0] + goff)
         tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
-        splits = max(1, min(Mred // 256, (768 + tiles - 1) // tiles))
+        # blocks in flight: ~1.5 per CU for the 128 x 32 tiles of dB (more splits only add atomics: 23 us at 384 blocks,
+        # 30 us at 768 for N = 512), ~3 per CU for the others (tools/probe/tn_splits.py)
+        target = 384 if Ko <= 96 else 768
+        splits = max(1, min(Mred // 256, (target + tiles - 1) // tiles))
         ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
                  ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=splits, alpha=alpha,
                  drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
@@ -445,17 +462,25 @@ class MegWhisperEngine:
         M = B * S
         assert x32.shape == (B, dims.ch, T) and x32.dtype == F32 and x32.is_contiguous()
         ops.signal_pack(x32, b["xin"], B, dims.ch, T, Cp)
-        c0, c1, c2 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"], self.conv_ops["conv2"]
+        c2 = self.conv_ops["conv2"]
         pb = lambda n: self.pview(f"model.encoder.{n}.bias")  # noqa: E731
-        # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
-        ops.gemm(A=b["xin"], am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
-                 bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d), g16m=rowmap(d, T, (T + 2) * d),
-                 flags=GELU_FWD)
-        # conv1.2 (k3,s2) + the encoder's outer GELU
         T2 = T // 2
-        ops.gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
-                 bias=pb("conv1.2"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
-                 g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
+        if self.frontend == "base":
+            c0, c1 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"]
+            # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
+            ops.gemm(A=b["xin"], am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
+                     bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d),
+                     g16m=rowmap(d, T, (T + 2) * d), flags=GELU_FWD)
+            # conv1.2 (k3,s2) + the encoder's outer GELU
+            ops.gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
+                     bias=pb("conv1.2"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
+                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
+        else:
+            # 'replace': one stride-2 conv over the packed signal + the encoder's outer GELU
+            cr = self.conv_ops["conv1"]
+            ops.gemm(A=b["xin"], am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
+                     bias=pb("conv1"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
+                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
         # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
         h = b["h"]
         ops.gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
@@ -716,7 +741,7 @@ class MegWhisperEngine:
         tmp = self._gbf[:N * r]
         tmp.zero_()
         ops.gemm(A=dy16, am=rowmap(ldy), K=Mred, B=u16, bm=rowmap(ldu), M=N, N=r, C32=tmp, ldc32=r,
-                 flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(Mred // 256, 192)))
+                 flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(Mred // 256, -(-384 // ((N + 127) // 128)))))
         en = ename or key + ".lora_E"
         ops.adalora_fold_grads(tmp, self.pview(key + ".lora_B"), (self.pview(en), eoff), self.gview(key + ".lora_B"),
                                (self.gview(en), eoff), N, r, s)
@@ -733,7 +758,7 @@ class MegWhisperEngine:
         dims, d = self.dims, self.dims.d
         B, S, T, Cp = b["B"], dims.src_pos, dims.T, dims.ch_pad
         T2, M = T // 2, B * S
-        c0, c1, c2 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"], self.conv_ops["conv2"]
+        c2 = self.conv_ops["conv2"]
         gp = lambda name: self.G.data_ptr() + 4 * self.seg_off[name][0]  # noqa: E731
         # d(pre2) = round16(dh) * gelu'(pre2), halo layout (B, S+2, d)
         ops.dgelu_mul(b["dh16"], b["pre2"], (b["dpre2"], d), rowmap(d, S, (S + 2) * d), M, d, pre_is_grad=True)
@@ -751,6 +776,12 @@ class MegWhisperEngine:
                  P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         dp1 = (b["dpre1"], d)
         hal1 = rowmap(d, T2, (T2 + 2) * d)
+        if self.frontend == "replace":
+            ops.colsum(b["dpre1"], gp("model.encoder.conv1.bias"), B * (T2 + 2), d, d)
+            self._wgrad(dp1, 0, b["xin"], 0, B * T2, d, 3 * Cp, "model.encoder.conv1.wp", am=hal1,
+                        bm=rowmap(2 * Cp, T2, (T + 2) * Cp))
+            return
+        c1 = self.conv_ops["conv1.2"]
         ops.colsum(b["dpre1"], gp("model.encoder.conv1.2.bias"), B * (T2 + 2), d, d)
         self._wgrad(dp1, 0, b["g0"], 0, B * T2, d, 3 * d, "model.encoder.conv1.2.wp", am=hal1,
                     bm=rowmap(2 * d, T2, (T + 2) * d))
@@ -818,10 +849,10 @@ class MegWhisperEngine:
     def conv_weight(self, name: str) -> torch.Tensor:
         """torch-layout (N, C, 3) view of a packed conv master (name in conv1.0 / conv1.2 / conv2)."""
         d = self.dims.d
-        cin, cp = (self.dims.ch, self.dims.ch_pad) if name == "conv1.0" else (d, d)
+        cin, cp = (self.dims.ch, self.dims.ch_pad) if name in ("conv1.0", "conv1") else (d, d)
         return self.pview(f"model.encoder.{name}.wp").view(d, 3, cp).permute(0, 2, 1)[:, :cin, :]
 
     def conv_weight_grad(self, name: str) -> torch.Tensor:
         d = self.dims.d
-        cin, cp = (self.dims.ch, self.dims.ch_pad) if name == "conv1.0" else (d, d)
+        cin, cp = (self.dims.ch, self.dims.ch_pad) if name in ("conv1.0", "conv1") else (d, d)
         return self.gview(f"model.encoder.{name}.wp").view(d, 3, cp).permute(0, 2, 1)[:, :cin, :]

@@ -61,7 +61,7 @@ def _gen(name: str, shape, std: float, seed: int, mean: float = 0.0) -> np.ndarr
     return (mean + std * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
 
 
-def make_state_dict(dims: WhisperDims, seed: int = 42) -> dict[str, np.ndarray]:
+def make_state_dict(dims: WhisperDims, seed: int = 42, frontend: str = "base") -> dict[str, np.ndarray]:
     """HF-named fp32 state dict of Whisper with the MEG front-end installed
     (reference: utils/model_utils.py:9-23 replaces encoder.conv1 by a Sequential whose
     state-dict keys are 0.weight/0.bias/2.weight/2.bias)."""
@@ -84,10 +84,14 @@ def make_state_dict(dims: WhisperDims, seed: int = 42) -> dict[str, np.ndarray]:
         lin(prefix + ".out_proj", d, d)
 
     e = "model.encoder."
-    sd[e + "conv1.0.weight"] = _gen(e + "conv1.0.weight", (d, dims.ch, 3), (3 * dims.ch) ** -0.5, seed)
-    sd[e + "conv1.0.bias"] = _gen(e + "conv1.0.bias", (d,), 0.1, seed)
-    sd[e + "conv1.2.weight"] = _gen(e + "conv1.2.weight", (d, d, 3), (3 * d) ** -0.5, seed)
-    sd[e + "conv1.2.bias"] = _gen(e + "conv1.2.bias", (d,), 0.1, seed)
+    if frontend == "replace":   # projection_module('replace'): one Conv1d(ch, d, k3, s2, p1) (utils/model_utils.py:19-21)
+        sd[e + "conv1.weight"] = _gen(e + "conv1.weight", (d, dims.ch, 3), (3 * dims.ch) ** -0.5, seed)
+        sd[e + "conv1.bias"] = _gen(e + "conv1.bias", (d,), 0.1, seed)
+    else:
+        sd[e + "conv1.0.weight"] = _gen(e + "conv1.0.weight", (d, dims.ch, 3), (3 * dims.ch) ** -0.5, seed)
+        sd[e + "conv1.0.bias"] = _gen(e + "conv1.0.bias", (d,), 0.1, seed)
+        sd[e + "conv1.2.weight"] = _gen(e + "conv1.2.weight", (d, d, 3), (3 * d) ** -0.5, seed)
+        sd[e + "conv1.2.bias"] = _gen(e + "conv1.2.bias", (d,), 0.1, seed)
     sd[e + "conv2.weight"] = _gen(e + "conv2.weight", (d, d, 3), (3 * d) ** -0.5, seed)
     sd[e + "conv2.bias"] = _gen(e + "conv2.bias", (d,), 0.1, seed)
     sd[e + "embed_positions.weight"] = _gen(e + "embed_positions.weight", (dims.src_pos, d), 0.3, seed)

@@ -39,9 +39,12 @@ def frontend(sd, x):
     """utils/model_utils.py:11-16 (Conv1d k3 p1 -> GELU -> Conv1d k3 s2 p1) then
     utils/load_model.py:410-416: gelu(conv1(x)), gelu(conv2(.)), permute, + embed_positions."""
     e = "model.encoder."
-    h = F.conv1d(x, sd[e + "conv1.0.weight"], sd[e + "conv1.0.bias"], stride=1, padding=1)
-    h = F.gelu(h)
-    h = F.conv1d(h, sd[e + "conv1.2.weight"], sd[e + "conv1.2.bias"], stride=2, padding=1)
+    if e + "conv1.weight" in sd:                     # projection_module('replace'): one stride-2 conv (model_utils.py:19-21)
+        h = F.conv1d(x, sd[e + "conv1.weight"], sd[e + "conv1.bias"], stride=2, padding=1)
+    else:
+        h = F.conv1d(x, sd[e + "conv1.0.weight"], sd[e + "conv1.0.bias"], stride=1, padding=1)
+        h = F.gelu(h)
+        h = F.conv1d(h, sd[e + "conv1.2.weight"], sd[e + "conv1.2.bias"], stride=2, padding=1)
     h = F.gelu(h)                                   # the encoder's own gelu(conv1(x))
     h = F.gelu(F.conv1d(h, sd[e + "conv2.weight"], sd[e + "conv2.bias"], stride=2, padding=1))
     h = h.permute(0, 2, 1)
@@ -165,7 +168,8 @@ def to_torch(sd_np, requires_grad=()):
 
 
 TRAINABLE_CONV = ("model.encoder.conv1.0.weight", "model.encoder.conv1.0.bias", "model.encoder.conv1.2.weight",
-                  "model.encoder.conv1.2.bias", "model.encoder.conv2.weight", "model.encoder.conv2.bias")
+                  "model.encoder.conv1.2.bias", "model.encoder.conv2.weight", "model.encoder.conv2.bias",
+                  "model.encoder.conv1.weight", "model.encoder.conv1.bias")
 
 
 def loss_and_grads(sd_np, lora_np, x_np, labels_np, dims, scale, orth_reg_weight=0.0):
@@ -177,7 +181,7 @@ def loss_and_grads(sd_np, lora_np, x_np, labels_np, dims, scale, orth_reg_weight
     if orth_reg_weight and lora:
         loss = loss + orth_reg_weight * adalora_orth_reg(lora)
     loss.backward()
-    grads = {k: sd[k].grad for k in TRAINABLE_CONV}
+    grads = {k: sd[k].grad for k in TRAINABLE_CONV if k in sd}
     if lora:
         grads.update({k: v.grad for k, v in lora.items()})
     return loss.detach(), logits.detach(), enc.detach(), grads

@@ -70,6 +70,33 @@ def test_finetune_first_layer_only_with_gradient_accumulation(dev, tmp_path):
     assert any(".layers.0." in k and "lora_A" in k for k in sd) and not any(".layers.1." in k and "lora" in k for k in sd)
 
 
+def test_finetune_and_evaluation_with_the_replace_frontend(dev, tmp_path):
+    """--config_name=replace (utils/model_utils.py:18-20): a single strided conv as `encoder.conv1`, trained as
+    modules_to_save and restored by evaluation.py."""
+    import evaluation
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 8, ch_file=24, name="toyset", seed=3, min_len=120, max_len=520)
+    out = str(tmp_path / "out")
+    common = ["--modal=eeg", "--eeg_ch=20", "--sampling_rate=200", "--timestamps=False", "--max_audio_len=2.0",
+              "--language=Dutch", "--num_workers=0", "--config_name=replace"]
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}",
+                   "--orig_sample_rate=200", "--use_adalora=False", "--fp16=True", "--num_train_epochs=2",
+                   "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
+                   "--eval_steps=100", "--save_steps=100", "--warmup_steps=0", "--learning_rate=1e-3",
+                   "--augment_config_path=None"] + common)
+    ck = os.path.join(out, "synthetic_tiny", "checkpoint-final")
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(ck, "adapter_model.safetensors"))
+    assert sd["base_model.model.model.encoder.conv1.weight"].shape == (256, 20, 3)
+    logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_tiny", "train_log.jsonl"))]
+    assert logs[-1]["loss"] < logs[0]["loss"]
+    evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                     "--max_new_tokens=6", "--num_beams=1"] + common)
+    res = json.load(open(os.path.join(ck, "formal_test_resultsno_post_processing.json")))
+    assert res["samples"] == 8
+
+
 def test_module_api_loss_backward_matches_engine(dev):
     """`.loss.backward()` through the nn.Module surface yields the engine's (unscaled) gradients; merged weights
     reproduce the adapted forward (merge_and_unload, evaluation.py:88-89)."""

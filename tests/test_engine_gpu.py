@@ -260,3 +260,28 @@ def test_gradient_accumulation_equals_one_big_batch(dev):
     eng.accumulate_step(xd[:2], ld[:2], 0, 2)
     eng.accumulate_step(xd[2:], ld[2:], 1, 2)
     assert eng.step_dev.item() == 1 and not torch.equal(eng.P, p0)
+
+
+def test_replace_frontend_forward_backward_vs_oracle(dev):
+    """projection_module('replace') (utils/model_utils.py:18-20): one Conv1d(ch, d, k3, s2) front-end."""
+    from neuspeech1_amd.engine import MegWhisperEngine, TrainCfg
+    from oracle import whisper_meg_oracle as O
+    dims = TINY
+    sd = make_state_dict(dims, 42, frontend="replace")
+    eng = MegWhisperEngine(dims, sd, train_cfg=TrainCfg(), device=dev)
+    assert eng.frontend == "replace"
+    x, labels = synth_batch(dims, 3, 31)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, o_logits, o_enc, og = O.loss_and_grads(sd, None, x, labels, dims, 0.0)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss.item(), o_loss.item())
+    assert rel(eng._b["enc16"].float().cpu().view(3, dims.src_pos, dims.d), o_enc) < 1e-2
+    s = eng.loss_scale_dev.item()
+    for nm in ("conv1", "conv2"):
+        assert rel(eng.conv_weight_grad(nm).float().cpu() / s, og[f"model.encoder.{nm}.weight"]) < 3e-2, nm
+        assert rel(eng.gview(f"model.encoder.{nm}.bias").cpu() / s, og[f"model.encoder.{nm}.bias"]) < 3e-2, nm
+    l0 = eng.train_step(xd, ld).item()
+    l1 = [eng.train_step(xd, ld).item() for _ in range(3)][-1]
+    assert l1 < l0

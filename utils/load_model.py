@@ -226,9 +226,9 @@ class WhisperForConditionalGeneration(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("the MI355X engine needs the model on a GPU (no CPU fallback for the product path)")
         conv = self.model.encoder.conv1
-        if not isinstance(conv, nn.Sequential):
+        if not isinstance(conv, nn.Sequential) and conv.stride != (2,):
             raise RuntimeError("install the MEG front-end first: model.model.encoder.set_input_embeddings("
-                               "projection_module('base', meg_ch=..., d_model=...))")
+                               "projection_module('base' | 'replace', meg_ch=..., d_model=...))")
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         lora, lora_sd = None, None
         if self._peft is not None:
@@ -250,13 +250,20 @@ class WhisperForConditionalGeneration(nn.Module):
 
     def _tie_trainables(self, eng):
         enc = self.model.encoder
-        for name, mod in (("conv1.0", enc.conv1[0]), ("conv1.2", enc.conv1[2]), ("conv2", enc.conv2)):
+        for name, mod in self._conv_modules():
             mod.weight.data = eng.conv_weight(name)
             mod.bias.data = eng.pview(f"model.encoder.{name}.bias")
         if self._peft is None:
             return
         for par, view in self._adapter_views(eng, eng.pview):
             par.data = view
+
+    def _conv_modules(self):
+        """(engine name, module) of the trainable convs: 'base' front-end = Sequential(conv, GELU, conv), 'replace' = one conv"""
+        enc = self.model.encoder
+        if isinstance(enc.conv1, nn.Sequential):
+            return (("conv1.0", enc.conv1[0]), ("conv1.2", enc.conv1[2]), ("conv2", enc.conv2))
+        return (("conv1", enc.conv1), ("conv2", enc.conv2))
 
     def _adapter_views(self, eng, getv):
         """(parameter, view of the engine's flat buffer) for every adapter tensor.  The engine pads the rank to a
@@ -369,7 +376,7 @@ def _grad_views(self, eng):
     """parameter storage pointer -> view of the engine gradient buffer with the parameter's shape"""
     out = {}
     enc = self.model.encoder
-    for name, mod in (("conv1.0", enc.conv1[0]), ("conv1.2", enc.conv1[2]), ("conv2", enc.conv2)):
+    for name, mod in self._conv_modules():
         out[mod.weight.data_ptr()] = eng.conv_weight_grad(name)
         out[mod.bias.data_ptr()] = eng.gview(f"model.encoder.{name}.bias")
     if self._peft is not None:

@@ -22,8 +22,8 @@ def projection_module(config_name="", **kwargs):
         )
         conv1.stride = (2,)   # lets the stock length check 1500*stride*stride = 6000 hold (reference :17)
         return conv1
-    if config_name == "replace":
-        raise NotImplementedError("config_name='replace' (single strided conv) is outside the HIP hot path; use 'base'")
+    if config_name == "replace":   # reference :18-20: one strided conv straight from the MEG channels
+        return nn.Conv1d(kwargs["meg_ch"], kwargs["d_model"], kernel_size=3, stride=2, padding=1)
     raise NotImplementedError(config_name)
 
 
