@@ -137,8 +137,13 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring256_kernel(const ns_gemm_d
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // stage s landed for every wave; every wave is done with stage s-1
     asm volatile("" ::: "memory");
+#ifdef NS_P8_STAMPS     // diagnostic build (tools/probe/gemm_ablate.py): flag bit 30 = no loads, bit 29 = no MFMA
     if (s + 1 < nsteps && !(p.flags & (1 << 30))) issue(s + 1);
     if (!(p.flags & (1 << 29))) compute(s & 1);
+#else
+    if (s + 1 < nsteps) issue(s + 1);
+    compute(s & 1);
+#endif
     if (DROP && seg2_first && s == steps2 - 1) {
       const float drop_inv = ns_drop_inv(p.drop_p);
       const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
