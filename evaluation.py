@@ -69,9 +69,14 @@ def main(argv=None):
     model = WhisperForConditionalGeneration.from_pretrained(args.model_path, device_map="auto",
                                                             local_files_only=args.local_files_only)
     torch.manual_seed(42)
-    conv1 = projection_module(config_name=args.config_name, meg_ch=args.eeg_ch,
-                              d_model=model.model.encoder.conv2.in_channels).to(model.device)
-    model.model.encoder.set_input_embeddings(conv1)
+    loaded = model.model.encoder.conv1
+    first = loaded[0] if isinstance(loaded, torch.nn.Sequential) else loaded
+    merged_export = args.lora_model is None and first.in_channels == args.eeg_ch and \
+        (isinstance(loaded, torch.nn.Sequential) or loaded.stride == (2,))
+    if not merged_export:     # a merged export (merge_lora.py) already carries its trained front-end: keep it
+        conv1 = projection_module(config_name=args.config_name, meg_ch=args.eeg_ch,
+                                  d_model=model.model.encoder.conv2.in_channels).to(model.device)
+        model.model.encoder.set_input_embeddings(conv1)
     out_dir = args.lora_model or "."
     if args.lora_model is not None:
         model = PeftModel.from_pretrained(model, args.lora_model, local_files_only=args.local_files_only)

@@ -83,6 +83,11 @@ def get_processor(name, language, task, timestamps, local_files_only):
         p = SyntheticProcessor(_SYNTH[name.split(":")[1]])
         p.tokenizer.set_prefix_tokens(language=language)
         return p
+    cfg_path = os.path.join(name, "config.json")
+    if os.path.exists(cfg_path):      # a model exported from a synthetic base (merge_lora.py / save_pretrained)
+        syn = json.load(open(cfg_path)).get("synthetic_name")
+        if syn:
+            return get_processor(f"synthetic:{syn}", language, task, timestamps, local_files_only)
     from transformers import WhisperProcessor
     return WhisperProcessor.from_pretrained(name, language=language, task=task, no_timestamps=not timestamps,
                                             local_files_only=local_files_only)

@@ -48,6 +48,19 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
                      "--teacher_forcing=True"] + common)
     res = json.load(open(os.path.join(ck, "formal_test_resultsno_post_processing_tf.json")))
     assert 0.0 <= res["teacher_forced_token_accuracy"] <= 1.0
+    # merge_lora.py: export the merged model, then decode from it WITHOUT the adapter: same hypotheses
+    import merge_lora
+    hyp_adapter = open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).read()
+    full = merge_lora.main([f"--lora_model={ck}", "--model_path=synthetic:tiny", "--eeg_ch=20"])
+    assert os.path.exists(os.path.join(full, "model.safetensors"))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        evaluation.main([f"--test_data={jl}", f"--model_path={full}", "--batch_size=4", "--max_new_tokens=8"] + common)
+        hyp_merged = open("formal_test_resultsno_post_processing.jsonl").read()
+    finally:
+        os.chdir(cwd)
+    assert hyp_merged == hyp_adapter
 
 
 def test_finetune_first_layer_only_with_gradient_accumulation(dev, tmp_path):

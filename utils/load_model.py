@@ -152,7 +152,9 @@ class WhisperForConditionalGeneration(nn.Module):
             parts = path.split(":")
             dm = _SYNTH[parts[1]]
             seed = int(parts[2]) if len(parts) > 2 else 42
-            model = cls(_cfg_from_dims(dm))
+            cfg0 = _cfg_from_dims(dm)
+            cfg0.synthetic_name = parts[1]       # travels in config.json: lets tools rebuild the synthetic processor
+            model = cls(cfg0)
             sd = {k: torch.from_numpy(v) for k, v in make_state_dict(dm, seed).items() if "conv1." not in k}
             model.load_state_dict(sd, strict=False)
         else:
@@ -164,6 +166,13 @@ class WhisperForConditionalGeneration(nn.Module):
             model = cls(cfg)
             from safetensors.torch import load_file
             sd = load_file(os.path.join(path, "model.safetensors"))
+            # a merged export (merge_lora.py) carries its MEG front-end: restore the module so its weights load
+            e = "model.encoder."
+            if e + "conv1.0.weight" in sd or (e + "conv1.weight" in sd and sd[e + "conv1.weight"].shape[1] != cfg.num_mel_bins):
+                from utils.model_utils import projection_module
+                w = sd.get(e + "conv1.0.weight", sd.get(e + "conv1.weight"))
+                model.model.encoder.set_input_embeddings(projection_module(
+                    config_name="base" if e + "conv1.0.weight" in sd else "replace", meg_ch=w.shape[1], d_model=cfg.d_model))
             own = model.state_dict()
             sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
             model.load_state_dict(sd, strict=False)
