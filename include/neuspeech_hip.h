@@ -57,7 +57,7 @@ enum {
   NS_GEMM_DGELU = 2,     /* C16 = round16(round16(acc) * gelu'(P16)) */
   NS_GEMM_TN = 4,        /* operands are reduction-major: A is (Kred x M) as X[m_red][m], see ns_gemm */
   NS_GEMM_ATOMIC32 = 8,  /* C32 += acc (fp32 atomics), for split reductions */
-  NS_GEMM_DROP_A = 16,   /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection) */
+  NS_GEMM_DROP_A = 16,   /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection; mask only) */
   NS_GEMM_GELU_SAVE_GRAD = 32, /* with NS_GEMM_GELU: C16 = round16(gelu'(x)) instead of x = round16(acc+bias): the backward then
                                   multiplies (NS_GEMM_MUL_P16) instead of re-evaluating erf / exp per element */
   NS_GEMM_MUL_P16 = 64   /* C16 = round16(round16(acc) * P16) */
@@ -108,9 +108,10 @@ typedef struct {
   float* C32; int32_t ldc32;
   int32_t flags;
   int32_t splits;           /* TN only: reduction split count (>=1) */
-  /* LoRA-dropout hook (NT dgrad): if drop_p > 0 the (A2,B2) product is formed
-     FIRST, multiplied element-wise by keep(seed,row,col)/(1-p), and the main
-     product accumulates on top.  For TN the mask multiplies operand B. */
+  /* LoRA-dropout hook (NT dgrad): if drop_p > 0 (<= 0.5) the (A2,B2) product is formed FIRST, multiplied
+     element-wise by the keep MASK keep(seed,row,col) (p quantised to thr8/256), and the main product accumulates on
+     top.  For TN the mask multiplies operand B, with NS_GEMM_DROP_A operand A.  The kernels never scale: the
+     survivors' 256/(256-thr8) belongs in the caller's alpha (of the down-projection / of the GEMM producing A2). */
   float drop_p; uint32_t drop_seed;
   float alpha;              /* acc is multiplied by alpha first (0 is read as 1) */
 } ns_gemm_desc;

@@ -76,6 +76,17 @@ __device__ __forceinline__ uint32_t ns_hash3(uint32_t seed, uint32_t a, uint32_t
 }
 __device__ __forceinline__ uint32_t ns_drop_thr8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
 __device__ __forceinline__ float ns_drop_inv(float p) { return 256.0f / (256.0f - (float)ns_drop_thr8(p)); }
+// The kernels apply the keep MASK only; the survivors' 1/(1 - thr8/256) rides in the caller's `alpha` (forward
+// down-projection, and the du GEMM of the backward), so no site multiplies per element.
+// Packed form for fp16 operands: bit 7 of byte e of `ge` = keep flag of element e (thr8 <= 128), expanded to two
+// dwords of half2 AND-masks.
+__device__ __forceinline__ void ns_keep_masks(uint32_t w, uint32_t thr8, uint32_t& m01, uint32_t& m23) {
+  const uint32_t ge = (((w & 0x7F7F7F7Fu) + (0x80u - thr8) * 0x01010101u) | w) & 0x80808080u;
+  const uint32_t f = ge >> 7;            // bytes 0 / 1
+  const uint32_t ff = (f << 8) - f;      // bytes 0x00 / 0xFF
+  m01 = __builtin_amdgcn_perm(ff, ff, 0x01010000u);
+  m23 = __builtin_amdgcn_perm(ff, ff, 0x03030202u);
+}
 __device__ __forceinline__ uint32_t ns_drop_word(uint32_t seed, uint32_t row, uint32_t col4) { return ns_hash3(seed, row, col4); }
 __device__ __forceinline__ bool ns_keep(uint32_t word, uint32_t col, uint32_t thr8) { return ((word >> ((col & 3) * 8)) & 0xFFu) >= thr8; }
 __device__ __forceinline__ bool ns_keep_el(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr8) {

@@ -72,7 +72,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float drop_inv = DROP ? ns_drop_inv(p.drop_p) : 1.f;
   const uint32_t drop_thr = DROP ? ns_drop_thr8(p.drop_p) : 0u;
 
   // ------------------------------------------------------------------ staging state
@@ -152,14 +151,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
       for (int it = 0; it < 4; ++it) {
         const uint32_t grow = (uint32_t)(m0 + st_row + 32 * it);
         uint32_t w[4] = {st.a[it].x, st.a[it].y, st.a[it].z, st.a[it].w};
-        const uint32_t dw[2] = {ns_drop_word(p.drop_seed, grow, (uint32_t)ko >> 2), ns_drop_word(p.drop_seed, grow, ((uint32_t)ko >> 2) + 1)};
+        uint32_t m[4];
+        ns_keep_masks(ns_drop_word(p.drop_seed, grow, (uint32_t)ko >> 2), drop_thr, m[0], m[1]);
+        ns_keep_masks(ns_drop_word(p.drop_seed, grow, ((uint32_t)ko >> 2) + 1), drop_thr, m[2], m[3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          half2v hv = __builtin_bit_cast(half2v, w[e]);
-          hv[0] = ns_keep(dw[e >> 1], 2 * e, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
-          hv[1] = ns_keep(dw[e >> 1], 2 * e + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
-          w[e] = __builtin_bit_cast(uint32_t, hv);
-        }
+        for (int e = 0; e < 4; ++e) w[e] &= m[e];
         st.a[it] = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
@@ -204,8 +200,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
             const uint32_t grow = (uint32_t)(kb + rl);
             half2v hv = __builtin_bit_cast(half2v, v);
             const uint32_t dwd = ns_drop_word(p.drop_seed, grow, (uint32_t)col >> 2);
-            hv[0] = ns_keep(dwd, (uint32_t)col, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
-            hv[1] = ns_keep(dwd, (uint32_t)col + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
+            hv[0] = ns_keep(dwd, (uint32_t)col, drop_thr) ? hv[0] : (half_t)0.f;
+            hv[1] = ns_keep(dwd, (uint32_t)col + 1, drop_thr) ? hv[1] : (half_t)0.f;
             v = __builtin_bit_cast(uint32_t, hv);
           }
         }
@@ -292,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
             for (int r = 0; r < 16; ++r) {
               const uint32_t row = (uint32_t)(m0 + wm * WAVE_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
               const uint32_t col = (uint32_t)(n0 + wn * WAVE_N + j * 32 + lr);
-              acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] * drop_inv : 0.f;
+              acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
             }
       }
       if (more) { if constexpr (TN) store_tn(cur ^ 1, NS_ST8); else store_nt(cur ^ 1, NS_ST8); }
@@ -396,7 +392,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   }
   if (d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU / MUL_P16 need P16");
   NS_CHECK_ARG(!(d->flags & NS_GEMM_GELU_SAVE_GRAD) || (d->flags & NS_GEMM_GELU), "ns_gemm: GELU_SAVE_GRAD needs GELU");
-  NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "ns_gemm: drop_p out of range");
+  NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p <= 0.5f, "ns_gemm: drop_p out of range (0 .. 0.5)");
 
   // skinny-N tiles (128x32) also serve small-M decode GEMMs: 4x more workgroups than 128x128 tiles when M <= 1024
   const bool skinny = !tn && (d->N <= 96 || (d->M <= 1024 && d->N <= 4096));

@@ -120,14 +120,18 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 
   const int steps1 = (p.K + BK - 1) / BK;
   const int steps2 = (p.K2 + BK - 1) / BK;
-  const int nsteps = steps1 + steps2;
   const bool seg2_first = DROP && steps2 > 0;
+  // with dropout the (A2, B2) product runs FIRST and is masked before the main product accumulates on top; its tile
+  // count is padded to even so that the mask falls between two passes of the (two-tile) loop body instead of sitting
+  // inside it (1.5 k instructions of mask code in the loop body cost 20-90 us per GEMM in instruction fetch alone)
+  const int steps2p = seg2_first ? (steps2 + 1) & ~1 : steps2;
+  const int nsteps = steps1 + steps2p;
 
   auto stage = [&](int tt, int region, int buf) __attribute__((always_inline)) {
     bool is2; int k0;
-    if (seg2_first) { is2 = tt < steps2; k0 = (is2 ? tt : tt - steps2) * BK; }
+    if (seg2_first) { is2 = tt < steps2p; k0 = (is2 ? tt : tt - steps2p) * BK; }
     else { is2 = tt >= steps1; k0 = (is2 ? tt - steps1 : tt) * BK; }
-    int klen = (is2 ? p.K2 : p.K) - k0;
+    int klen = (is2 ? p.K2 : p.K) - k0;     // <= 0 past the segment's end (padding tiles): fetched as zeros
     if (tt >= nsteps) klen = 0;
 #ifdef NS_P8_STAMPS
     if (p.flags & (1 << 30)) return;   // diagnostic build: no loads
@@ -206,24 +210,6 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     NS_P8_RUN(1, 1);
     stage(t + 2, RB0, b);
     NS_P8_RUN(1, 0);
-    if (DROP && seg2_first && t == steps2 - 1) {
-      const float drop_inv = ns_drop_inv(p.drop_p);
-      const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
-              const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
-              const uint32_t w = ns_drop_word(p.drop_seed, row, col >> 2);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] * drop_inv : 0.f;
-            }
-    }
   };
 
   // prologue: tile 0 complete + the first two regions of tile 1
@@ -236,7 +222,30 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
   NS_P8_BARRIER();
   NS_STAMP(2);
   if (wm == 1) NS_P8_BARRIER();     // group 1 runs one barrier interval behind group 0
-  for (int t = 0; t < nsteps; t += 2) {
+  int t = 0;
+  if (DROP && seg2_first) {
+    for (; t < steps2p; t += 2) {
+      tile(t, 0);
+      tile(t + 1, 1);
+    }
+    // LoRA-dropout mask on the (A2, B2) product (the DMA pieces of the next tiles stay in flight meanwhile)
+      const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
+            const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
+            const uint32_t w = ns_drop_word(p.drop_seed, row, col >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] : 0.f;
+          }
+  }
+  for (; t < nsteps; t += 2) {
     tile(t, 0);
     tile(t + 1, 1);
   }

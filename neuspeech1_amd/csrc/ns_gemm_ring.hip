@@ -143,7 +143,6 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     if (s + NST - 1 < nsteps) issue(s + NST - 1);   // refills the buffer slice s-1 lived in
     compute(s % NST);
     if (DROP && seg2_first && s == steps2 - 1) {
-      const float drop_inv = ns_drop_inv(p.drop_p);
       const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
           for (int r = 0; r < 16; ++r) {
             const uint32_t row = (uint32_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
             const uint32_t col = (uint32_t)(n0 + wn * 64 + j * 32 + lr);
-            acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] * drop_inv : 0.f;
+            acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
           }
     }
   }

@@ -65,7 +65,6 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const float drop_inv = DROP ? ns_drop_inv(p.drop_p) : 1.f;
   const uint32_t drop_thr = DROP ? ns_drop_thr8(p.drop_p) : 0u;
 
   // column chunk of this thread (clamped into the valid range: redundant but in-bounds, results discarded)
@@ -95,14 +94,11 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
       if (DROP) {
         const uint32_t grow = (uint32_t)(k_begin + step * BKM + rl);
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t dw[2] = {ns_drop_word(p.drop_seed, grow, (uint32_t)colb >> 2), ns_drop_word(p.drop_seed, grow, ((uint32_t)colb >> 2) + 1)};
+        uint32_t m[4];
+        ns_keep_masks(ns_drop_word(p.drop_seed, grow, (uint32_t)colb >> 2), drop_thr, m[0], m[1]);
+        ns_keep_masks(ns_drop_word(p.drop_seed, grow, ((uint32_t)colb >> 2) + 1), drop_thr, m[2], m[3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          half2v hv = __builtin_bit_cast(half2v, w[e]);
-          hv[0] = ns_keep(dw[e >> 1], 2 * e, drop_thr) ? (half_t)((float)hv[0] * drop_inv) : (half_t)0.f;
-          hv[1] = ns_keep(dw[e >> 1], 2 * e + 1, drop_thr) ? (half_t)((float)hv[1] * drop_inv) : (half_t)0.f;
-          w[e] = __builtin_bit_cast(uint32_t, hv);
-        }
+        for (int e = 0; e < 4; ++e) w[e] &= m[e];
         v = make_uint4(w[0], w[1], w[2], w[3]);
       }
       rb[it] = v;

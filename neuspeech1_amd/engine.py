@@ -442,6 +442,12 @@ class MegWhisperEngine:
     def _drop_p(self):
         return self.lora.dropout if (self.lora and self.training_mode) else 0.0
 
+    def _drop_inv(self):
+        """1/(1-p) of the survivors, p quantised like the kernels' byte mask (thr8/256).  The kernels apply the mask
+        only; this factor rides in the alpha of the GEMM that produces the LoRA bottleneck (u forward, du backward)."""
+        p = self._drop_p()
+        return 256.0 / (256.0 - int(p * 256.0 + 0.5)) if p > 0 else 1.0
+
     def _wgrad(self, dy16, ldy, x16, ldx, Mred, No, Ko, gname, alpha=1.0, goff=0, ldc=None, drop=False,
                am=None, bm=None):
         gptr = self.G.data_ptr() + 4 * (self.seg_off[gname][0] + goff)
@@ -501,7 +507,7 @@ class MegWhisperEngine:
             ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
             if r:
                 ops.gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
-                         c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed)
+                         c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
                 self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j], A2=b["uqkv"][j], lda2=3 * r, K2=r, B2=lo["sBqkv"],
                           ngroup=d)
             else:
@@ -511,18 +517,18 @@ class MegWhisperEngine:
                          ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j])
             if r:
                 ops.gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
-                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 1)
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 1)
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"])
             else:
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid)
             ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
             if r:
                 ops.gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
-                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 2)
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True, A2=b["u1"][j], lda2=r,
                           K2=r, B2=lo["fc1_sB"])
                 ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
-                         flags=NS_GEMM_DROP_A if dp > 0 else 0, drop_p=dp, drop_seed=seed + 3)
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 3)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
             else:
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True)
@@ -673,8 +679,9 @@ class MegWhisperEngine:
             seed = self._layer_seed(i)
             dy = b["dh16"]
             if r:
-                # fc2: du = dy*sB ; dB = s*dy^T u ; dA = du^T gf_d ; dgf = dy*W + mask(du*A)
-                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["fc2_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                # fc2: du = dy*sB / keep ; dB = s*dy^T u ; dA = du^T mask(gf) ; dgf = dy*W + mask * (du*A)
+                # (the kernels apply the dropout MASK only: 1/keep rides in du's alpha, forward in u's alpha)
+                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["fc2_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
                 self._cur_seed_save = self._cur_seed
                 self._wgrad_b(dy, d, b["u2"][i], r, M, d, p + "fc2", sc)
                 self._with_seed(seed + 3, lambda: self._wgrad(b["du"], r, b["gf"][i], f, M, r, f, p + "fc2.lora_A", drop=True))
@@ -682,7 +689,7 @@ class MegWhisperEngine:
                                                                lda2=r, K2=r, B2=lo["fc2_AT"], drop=True))
                 # fc1
                 dpf = b["dpre_f"]
-                ops.gemm(A=dpf, am=rowmap(f), K=f, B=lo["fc1_sBT"], ldb=f, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                ops.gemm(A=dpf, am=rowmap(f), K=f, B=lo["fc1_sBT"], ldb=f, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
                 self._wgrad_b(dpf, f, b["u1"][i], r, M, f, p + "fc1", sc)
                 self._with_seed(seed + 2, lambda: self._wgrad(b["du"], r, b["x2"][i], d, M, r, d, p + "fc1.lora_A", drop=True))
                 self._with_seed(seed + 2, lambda: self._dgrad(dpf, M, Lw["fc1"], b["dx16"], A2=b["du"], lda2=r, K2=r,
@@ -693,7 +700,7 @@ class MegWhisperEngine:
             ops.layernorm_bwd(b["dx16"], False, hmid, *b["st2"][i], Lw["ln2"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
             dy = b["dh16"]
             if r:
-                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["out_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r))
+                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["out_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
                 self._wgrad_b(dy, d, b["uo"][i], r, M, d, p + "self_attn.out_proj", sc)
                 self._with_seed(seed + 1, lambda: self._wgrad(b["du"], r, b["ao"][i], d, M, r, d,
                                                                p + "self_attn.out_proj.lora_A", drop=True))
@@ -708,7 +715,7 @@ class MegWhisperEngine:
             if r:
                 for j, (nm, key, a) in enumerate((("q_proj", "sBqT", sc * qs), ("k_proj", "sBkT", sc), ("v_proj", "sBvT", sc))):
                     ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=d, B=lo[key], ldb=d, M=M, N=r, C16=(b["du3"], j * r),
-                             c16m=rowmap(3 * r))
+                             c16m=rowmap(3 * r), alpha=self._drop_inv())
                     self._wgrad_b((dqkv, j * d), 3 * d, (b["uqkv"][i], j * r), 3 * r, M, d, p + f"self_attn.{nm}", a,
                                   ename=p + "self_attn.qkv.lora_E", eoff=j * r)
                 self._with_seed(seed, lambda: self._wgrad(b["du3"], 3 * r, b["x1"][i], d, M, 3 * r, d,

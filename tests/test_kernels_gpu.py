@@ -369,15 +369,17 @@ def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
     xd = (x.float() * keep * inv).half()       # what the kernels see after masking (rounded like they round)
     # forward down-projection: u = drop(x) A^T
     u = torch.empty(M, r, device=dev, dtype=torch.float16)
+    # (the kernels apply the mask only; the survivors' 1/keep rides in alpha, here and in the GEMM producing du)
     ops.gemm(A=x, am=ops.rowmap(K), K=K, B=A, ldb=K, M=M, N=r, C16=u, c16m=ops.rowmap(r), flags=ops.NS_GEMM_DROP_A,
-             drop_p=p, drop_seed=seed)
+             alpha=inv, drop_p=p, drop_seed=seed)
     close(u, xd.float() @ A.float().T, 1e-2, 5e-3, "dropout down-projection")
     # dgrad: dx = dy W + mask * (du A) / (1-p)   (all three GEMM kernels that carry the mask)
     dy, W = rnd((M, N), dev, 0.5, seed=3), rnd((N, K), dev, 0.05, seed=4)
-    du, AT = rnd((M, r), dev, 0.5, seed=5), A.t().contiguous()
-    ref = dy.float() @ W.float() + keep * inv * (du.float() @ A.float())
+    du0, AT = rnd((M, r), dev, 0.5, seed=5), A.t().contiguous()
+    du = (du0.float() * inv).half()           # what the engine's du GEMM emits (alpha = 1/keep)
+    ref = dy.float() @ W.float() + keep * (du.float() @ A.float())
     from neuspeech1_amd import lib
-    for mode in (0, 2, 3):
+    for mode in (0, 2, 3, 4):
         lib.load().ns_debug_set_ring(mode)
         dx = torch.empty(M, K, device=dev, dtype=torch.float16)
         ops.gemm(A=dy, am=ops.rowmap(N), K=N, B=W.t().contiguous(), ldb=N, M=M, N=K, A2=du, am2=ops.rowmap(r), K2=r,
@@ -387,5 +389,5 @@ def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
         dA = torch.zeros(r, K, device=dev)
         ops.gemm(A=du, am=ops.rowmap(r), K=M, B=x, bm=ops.rowmap(K), M=r, N=K, C32=dA, ldc32=K,
                  flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=3, drop_p=p, drop_seed=seed)
-        close(dA, du.float().T @ xd.float(), 3e-2, 3e-3, f"dropout wgrad (ring mode {mode})")
+        close(dA, du.float().T @ (x.float() * keep), 3e-2, 3e-3, f"dropout wgrad (ring mode {mode})")
     lib.load().ns_debug_set_ring(1)
