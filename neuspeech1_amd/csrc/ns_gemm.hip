@@ -395,7 +395,9 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p <= 0.5f, "ns_gemm: drop_p out of range (0 .. 0.5)");
 
   // skinny-N tiles (128x32) also serve small-M decode GEMMs: 4x more workgroups than 128x128 tiles when M <= 1024
-  const bool skinny = !tn && (d->N <= 96 || (d->M <= 1024 && d->N <= 4096));
+  // (large-M N = 96 -- the stacked q|k|v LoRA bottleneck -- goes to the 128-wide tile: one pass over A, and one dropout
+  // hash per element, instead of three 32-wide column tiles each re-reading and re-masking it)
+  const bool skinny = !tn && ((d->N <= 96 && !(d->M >= 4096 && d->N > 32)) || (d->M <= 1024 && d->N <= 4096));
   const bool drop = d->drop_p > 0.f;
   const int bn = skinny ? 32 : 128;
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
