@@ -16,9 +16,10 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, grad_flat: torch.Tensor, group=None):
+    def __init__(self, grad_flat: torch.Tensor, group=None, force: bool = False):
         self.G = grad_flat
         self.group = group
+        self.force = force        # run the collective even at world size 1 (tests of the stream / event plumbing)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = grad_flat.is_cuda
         self.side = torch.cuda.Stream(device=grad_flat.device) if self.cuda else None
@@ -28,7 +29,7 @@ class GradReducer:
 
     def on_ready(self, lo: int, hi: int):
         """G[lo:hi] is final on the current stream: start its all-reduce on the side stream."""
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.force) or hi <= lo:
             return
         self.chunks.append((lo, hi))
         view = self.G[lo:hi]
@@ -50,6 +51,6 @@ class GradReducer:
 
     def finish(self):
         """Make the optimizer (current stream) wait for every chunk."""
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.force):
             torch.cuda.current_stream().wait_stream(self.side)
         self.chunks.clear()

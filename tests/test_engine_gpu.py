@@ -285,3 +285,39 @@ def test_replace_frontend_forward_backward_vs_oracle(dev):
     l0 = eng.train_step(xd, ld).item()
     l1 = [eng.train_step(xd, ld).item() for _ in range(3)][-1]
     assert l1 < l0
+
+
+def test_rccl_reducer_on_the_side_stream_single_rank(dev):
+    """The DP plumbing on a real GPU: RCCL (backend "nccl") all-reduce AVG of the gradient chunks on the side stream,
+    gated by events, with one rank (the collective is the identity): the steps must equal the plain steps up to the
+    run-to-run last-bit noise of the fp32-atomic weight-gradient sums."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from neuspeech1_amd.dp import GradReducer
+    dims = TINY
+    x, labels = synth_batch(dims, 3, 77)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng_a, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    eng_b, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        red = GradReducer(eng_b.G, force=True)
+        calls = []
+        def on_ready(lo, hi):
+            calls.append((lo, hi))
+            red.on_ready(lo, hi)
+        for _ in range(3):
+            la = eng_a.train_step(xd, ld)
+            lb = eng_b.train_step(xd, ld, on_ready=on_ready, reduce_fn=red.finish)
+        torch.cuda.synchronize()
+        assert len(calls) == 9 and calls[0][0] < calls[0][1]          # 2 adapter chunks + the conv stem, per step
+        assert sorted(calls[:3])[0][0] == 0 and max(h for _, h in calls[:3]) == eng_b.n_train
+        torch.testing.assert_close(eng_b.P, eng_a.P, atol=2e-5, rtol=1e-4)
+        assert abs(la.item() - lb.item()) < 1e-4 * max(1.0, abs(la.item()))
+    finally:
+        dist.destroy_process_group()
