@@ -185,7 +185,8 @@ void launch_tn(const ns_gemm_desc* d, hipStream_t st) {
 // called by ns_gemm() for TN descriptors whose M, N and row strides are multiples of 8 (arguments already validated)
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st) {
   const bool drop = d->drop_p > 0.f;
-  if (d->M <= 96) { if (drop) launch_tn<32, 128, true>(d, st); else launch_tn<32, 128, false>(d, st); }
+  // (M in (32, 128] -- the stacked q|k|v bottleneck, 3r = 96 rows -- takes the 128-row tile: B is read, and masked, once)
+  if (d->M <= 32) { if (drop) launch_tn<32, 128, true>(d, st); else launch_tn<32, 128, false>(d, st); }
   else if (d->N <= 96) { if (drop) launch_tn<128, 32, true>(d, st); else launch_tn<128, 32, false>(d, st); }
   else { if (drop) launch_tn<128, 128, true>(d, st); else launch_tn<128, 128, false>(d, st); }
   return 0;

@@ -454,7 +454,7 @@ class MegWhisperEngine:
         tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
         # blocks in flight: ~1.5 per CU for the 128 x 32 tiles of dB (more splits only add atomics: 23 us at 384 blocks,
         # 30 us at 768 for N = 512), ~3 per CU for the others (tools/probe/tn_splits.py)
-        target = 384 if Ko <= 96 else 768
+        target = 384 if (Ko <= 96 or 32 < No <= 128) else 768
         splits = max(1, min(Mred // 256, (target + tiles - 1) // tiles))
         ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
                  ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=splits, alpha=alpha,

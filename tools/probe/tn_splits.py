@@ -17,7 +17,7 @@ def t(fn, n=10):
         best = min(best, e0.elapsed_time(e1) / n)
     return best
 for name, No, Ko, drop in (("dB N=512", 512, 32, 0.0), ("dB N=2048", 2048, 32, 0.0), ("dB N=1536(q|k|v: 3 x 512)", 512, 32, 0.0),
-                           ("dA K=512 drop", 32, 512, 0.05), ("dA K=2048 drop", 32, 2048, 0.05), ("dA K=512", 32, 512, 0.0)):
+                           ("dA K=512 drop", 32, 512, 0.05), ("dA q|k|v (3r=96) K=512 drop", 96, 512, 0.05), ("dA K=2048 drop", 32, 2048, 0.05), ("dA K=512", 32, 512, 0.0)):
     A, B = rnd(M, No), rnd(M, Ko)
     C = torch.zeros(No, Ko, device=dev)
     row = []
