@@ -125,3 +125,9 @@ timeit("layernorm fwd 96000x512", lambda: ops.layernorm_fwd(h32, gam, gam, y16, 
 timeit("layernorm bwd 96000x512", lambda: ops.layernorm_bwd(y16, False, h32, mean, rstd, gam, h32, h32o, y16, M, d), 0, M * d * 16)
 xs = rnd(B, 208, T, dtype=F32)
 timeit("signal_pack 64x208x6000", lambda: ops.signal_pack(xs, xin, B, 208, T, Cp), 0, B * 208 * T * 4 + B * T * Cp * 2)
+
+# conv bias gradients: column sums of d(pre) in halo layout
+for name, rows_ in (("colsum 64x6000x512", 64 * 6000), ("colsum 64x3002x512", 64 * 3002)):
+    a_ = rnd(rows_, 512)
+    o_ = torch.zeros(512, device=dev)
+    timeit(name, lambda: ops.colsum(a_, o_, rows_, 512, 512), 0.0, rows_ * 512 * 2)
