@@ -167,6 +167,10 @@ def load() -> C.CDLL:
         raise NeuSpeechHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the product path)")
+    # torch first: the library links libamdhip64 by soname, and the process must end up with ONE HIP runtime -- the one
+    # torch brought (its streams / allocations are what the kernels are launched on).  Loaded the other way round, the
+    # library binds /opt/rocm's runtime and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
