@@ -155,7 +155,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the 256x256 LDS-DMA ring GEMM: one extra instrumented step, HIP events on the launch stream
         ops.GEMM_PROFILE = []
-        step()
+        eng.train_step(xd, ld)      # local step, NO collective: only rank 0 runs this instrumented extra step
         torch.cuda.synchronize()
         recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         tot = {}
