@@ -119,6 +119,7 @@ def main():
     B = args.batch
     sd = make_state_dict(dims, 42)          # identical seeded init on every rank (no broadcast needed)
     spec = LoraSpec(r=args.lora_r, alpha=2.0 * args.lora_r, dropout=0.05)
+    torch.manual_seed(42)                   # the adapters' kaiming init must be the same replica on every rank
     eng = MegWhisperEngine(dims, sd, lora=spec, lora_sd=None,
                            train_cfg=TrainCfg(lr=1e-3, warmup_steps=500, total_steps=100000), device=dev)
     del sd
