@@ -16,7 +16,14 @@ __all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pa
            "NS_GEMM_MUL_P16"]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's CURRENT stream on the current device (graph capture and the DP side stream switch it).
+    The raw accessor is ~20x cheaper than torch.cuda.current_stream(): 374 launches per training step call this."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
