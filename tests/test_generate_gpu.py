@@ -156,3 +156,26 @@ def test_graph_replay_gives_the_same_ids_as_eager_launches(setup, nb):
     b = Generator(gen.eng, use_graph=True, graph_min_steps=0).generate(x, prompt, **kw)
     c = Generator(gen.eng, use_graph=True, graph_min_steps=0).generate(x, prompt, check_every=1, **kw)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("name,nb,kw", [
+    ("greedy", 1, {}),
+    ("greedy_rp", 1, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("beam5", 5, {}),
+    ("beam5_rp", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+])
+def test_token_ids_exact_at_whisper_base_dims(dev, name, nb, kw):
+    """Same bar at the size BASELINE's metrics are quoted on (whisper-base, 208-ch MEG): ids from the reference
+    object (tools/make_goldens.py decode_base), B = 2, 16 new tokens."""
+    from neuspeech1_amd.engine import MegWhisperEngine
+    from neuspeech1_amd.generate import Generator
+    from neuspeech1_amd.weights import WHISPER_BASE
+    g = np.load(os.path.join(G, "decode_base208.npz"))
+    dims = WHISPER_BASE
+    gen = Generator(MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev))
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    out = gen.generate(torch.from_numpy(x).to(dev), torch.from_numpy(labels[:, :4].copy()).to(dev), num_beams=nb,
+                       max_new_tokens=int(g["new_tokens"]), check_every=1, **kw)
+    check(out, g[name], dims.pad_id)
+    if nb > 1:
+        np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[name + "_scores"], atol=2e-2)

@@ -111,7 +111,7 @@ def lora_golden(dims, tag, B, r=32, alpha=64.0):
     print(f"lora_merged_{tag}: loss {out.loss.item():.6f}")
 
 
-def decode_golden(dims, tag, B, new_tokens):
+def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630)):
     import transformers
     sd_np = make_state_dict(dims, 42)
     model = build_hf(dims, sd_np)
@@ -136,7 +136,7 @@ def decode_golden(dims, tag, B, new_tokens):
         g["beam5"] = o.sequences.numpy()
         g["beam5_scores"] = o.sequences_scores.numpy().astype(np.float32)
         # EOS variants: declare a frequently generated token id as EOS so rows / hypotheses really finish
-        for eos in (34, 630):
+        for eos in eos_variants:
             c2 = dict(common, eos_token_id=eos)
             o = gen(model, feats, num_beams=1, **c2)
             g[f"greedy_eos{eos}"] = o.sequences.numpy()
@@ -162,6 +162,9 @@ if __name__ == "__main__":
         lora_golden(TINY, "tiny", B=2)
     if "decode" in what:
         decode_golden(TINY, "tiny", B=3, new_tokens=24)
+    if "decode_base" in what:
+        # BASELINE dims (whisper-base, 208-ch): token-id parity at the size the metric is quoted on
+        decode_golden(WHISPER_BASE, "base208", B=2, new_tokens=16, eos_variants=())
 
 
 def reader_golden():
