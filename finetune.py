@@ -73,6 +73,8 @@ def build_parser():
     add_arg("ft_full", type=bool, default=False, help="adapt the whole model")
     # additions of this build (not in the reference)
     add_arg("max_steps", type=int, default=-1, help="stop after N optimizer steps (smoke runs)")
+    add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack) "
+                                                        "instead of in the data-loader workers")
     return parser
 
 
@@ -119,23 +121,31 @@ def evaluate_loss(model, dataset, collator, batch_size, rank, world, num_workers
 
 
 class DevicePrefetcher:
-    """Host -> device feed of the collated batches on a copy stream, one batch ahead of the step that consumes it
-    (pinned source, so the 319 MB fp32 batch of BASELINE configs[1] moves under the previous step instead of in
-    front of this one).  Yields (input_features, labels) device tensors."""
+    """Host -> device feed of the collated batches on a copy stream, one batch ahead of the step that consumes it.
+    Yields (input_features, labels) on the device.  Two sources:
+      * float32 (B, ch, T) tensors from the collator (pinned, so the 319 MB batch of BASELINE configs[1] moves under
+        the previous step instead of in front of this one);
+      * lists of RawSignal (CustomDataset(raw_signals=True)): the recordings' bytes go through
+        neuspeech1_amd.feed.SignalFeed and arrive as a PackedSignal -- release() it once its step is enqueued."""
 
-    def __init__(self, loader, device):
-        self.loader, self.device = loader, device
+    def __init__(self, loader, device, feed=None):
+        self.loader, self.device, self.feed = loader, device, feed
         self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
 
     def _load(self, it):
         batch = next(it, None)
         if batch is None:
             return None
+        x = batch["input_features"]
+        if isinstance(x, list):
+            assert self.feed is not None, "RawSignal batches need a SignalFeed"
+            with torch.cuda.stream(self.stream):
+                y = batch["labels"].pin_memory().to(self.device, non_blocking=True)
+            return self.feed.submit(x), y       # Future: the reads run on the feed's loader thread
         if self.stream is None:
-            return batch["input_features"].to(self.device), batch["labels"].to(self.device)
+            return x.to(self.device), batch["labels"].to(self.device)
         with torch.cuda.stream(self.stream):
-            return (batch["input_features"].to(self.device, non_blocking=True),
-                    batch["labels"].to(self.device, non_blocking=True))
+            return x.to(self.device, non_blocking=True), batch["labels"].to(self.device, non_blocking=True)
 
     def __iter__(self):
         it = iter(self.loader)
@@ -143,8 +153,11 @@ class DevicePrefetcher:
         while nxt is not None:
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
+                if not isinstance(nxt[0], torch.Tensor):
+                    nxt = (nxt[0].result().acquire(), nxt[1])
                 for t in nxt:
-                    t.record_stream(torch.cuda.current_stream())
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(torch.cuda.current_stream())
             cur, nxt = nxt, self._load(it)
             yield cur
 
@@ -177,6 +190,7 @@ def main(argv=None):
                                   split_sentences=args.split_sentences, augment_config_path=args.augment_config_path,
                                   **ds_kw)
     test_dataset = CustomDataset(data_list_path=args.test_data, mode="val", **ds_kw)
+    train_dataset.raw_signals = bool(args.device_feed) and torch.cuda.is_available() and args.device != "cpu"
     if args.data_ratio is not None:
         train_dataset.data_list = get_part_of_dataset(train_dataset.data_list, args.data_ratio)
     print(f"train samples: {len(train_dataset)}, eval samples: {len(test_dataset)}")
@@ -263,6 +277,11 @@ def main(argv=None):
     eng.drop_seed = 42 + rank
     reducer = GradReducer(eng.G) if ddp else None
 
+    feed = None
+    if train_dataset.raw_signals:
+        from neuspeech1_amd.feed import SignalFeed
+        feed = SignalFeed(whisper.device, eng.dims.ch, eng.dims.T, eng.dims.ch_pad, threads=max(2, args.num_workers))
+
     step, best, t_log, n_log = 0, float("inf"), time.time(), 0
     log_path = os.path.join(output_dir, "train_log.jsonl")
     done = False
@@ -271,7 +290,7 @@ def main(argv=None):
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(train_dataset, idx), batch_size=B, shuffle=False,
                                              num_workers=args.num_workers, collate_fn=data_collator, drop_last=False,
                                              pin_memory=True)
-        for group in grouped(DevicePrefetcher(loader, whisper.device), accum):
+        for group in grouped(DevicePrefetcher(loader, whisper.device, feed), accum):
             rk = dict(on_ready=reducer.on_ready, reduce_fn=reducer.finish) if reducer is not None else {}
             if len(group) == 1:
                 loss = eng.train_step(group[0][0], group[0][1], **rk)
@@ -280,6 +299,9 @@ def main(argv=None):
                 loss = torch.stack(micro).mean()
             step += 1
             n_log += sum(x.shape[0] for x, _ in group)
+            for x, _ in group:
+                if hasattr(x, "release"):
+                    x.release()         # the step reading this staged batch is enqueued: its slot may be refilled
             if step % args.logging_steps == 0 and rank == 0:
                 dt = time.time() - t_log
                 rec = {"step": step, "epoch": round(step / steps_per_epoch, 3), "loss": round(loss.item(), 5),

@@ -144,6 +144,31 @@ int ns_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float*
  * ---------------------------------------------------------------------- */
 int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream);
 
+/* ------------------------------------------------------------------------
+ * ns_feed_pack: the reader's crop / pad / cast rules as ONE device pass over
+ * the raw recordings.  Item b describes recording b as
+ * it sits in a device staging buffer: the channel rows the reader keeps
+ * (utils/reader.py:282-290: schoffelen [28:301], gwilliams [:208], else
+ * [:modal_ch]), `n` samples each, in the file's own dtype.  The kernel
+ *   - zero-fills channels [rows, ch)            (pad_sample_ch, reader.py:508-516)
+ *   - crops at T and zero-fills samples [n, T)  (padding_sample, reader.py:496-506)
+ *   - rounds to fp32 exactly like the collator  (utils/data_utils.py:191-193)
+ *   - and emits what ns_signal_pack emits: (B, T+2, Cp) fp16 with zero halo rows;
+ *     x32 (optional) receives the collator's own (B, ch, T) fp32 tensor.
+ * rows <= ch is required (the reader asserts the same shape).
+ * ---------------------------------------------------------------------- */
+enum { NS_FEED_F64 = 0, NS_FEED_F32 = 1, NS_FEED_F16 = 2 };
+typedef struct ns_feed_item {
+  const void* src;   /* device pointer to element [row 0][sample 0] of the kept rows, aligned to its dtype */
+  long long ld;      /* elements between consecutive channel rows */
+  int rows;          /* channel rows present, 0 .. ch */
+  int n;             /* samples present per row, >= 0 (cropped at T) */
+  int dtype;         /* NS_FEED_* */
+  int reserved;
+} ns_feed_item;
+int ns_feed_pack(const ns_feed_item* items_dev, int B, int ch, int T, int Cp, void* out16, float* x32,
+                 void* stream);
+
 /* h32[row] = E32[ids[row]] + P32[pos0 + row % L]; pos0_dev (optional) overrides
  * pos0 from device memory (decode step counter).  utils/load_model.py:645,668-673 */
 int ns_embed_pos(const int64_t* ids, const float* E32, const float* P32, float* h32, int rows, int L, int d,

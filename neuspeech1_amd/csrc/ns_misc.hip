@@ -53,6 +53,52 @@ __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restric
   }
 }
 
+// Raw recordings -> the same (B, T+2, Cp) fp16 layout, with the reader's channel / time zero padding and the
+// collator's f64 -> f32 rounding applied on the way (see ns_feed_pack in the header).  Same tiling as
+// signal_pack_kernel; a block that lies wholly in a recording's padding issues no loads at all.
+template <typename SRC>
+__device__ __forceinline__ float feed_load(const void* src, long long idx) { return (float)((const SRC*)src)[idx]; }
+
+__global__ __launch_bounds__(256) void feed_pack_kernel(const ns_feed_item* __restrict__ items, half_t* __restrict__ out,
+                                                         float* __restrict__ x32, int ch, int T, int Cp) {
+  __shared__ half_t tile[64][66];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const ns_feed_item it = items[b];
+  const int rows = min(it.rows, ch), n = min(it.n, T);
+  const bool live = c0 < rows && t0 < n;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + w * 16 + i, t = t0 + lane;
+    float v = 0.f;
+    if (live && c < rows && t < n) {
+      const long long idx = (long long)c * it.ld + t;
+      v = it.dtype == NS_FEED_F64 ? feed_load<double>(it.src, idx)
+          : it.dtype == NS_FEED_F32 ? feed_load<float>(it.src, idx) : feed_load<half_t>(it.src, idx);
+    }
+    tile[w * 16 + i][lane] = (half_t)v;
+    if (x32 && c < ch && t < T) x32[((size_t)b * ch + c) * T + t] = v;
+  }
+  __syncthreads();
+  half_t* ob = out + (size_t)b * (T + 2) * Cp;
+  const int cc = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int tl = (threadIdx.x >> 3) + 32 * k;
+    const int t = t0 + tl;
+    if (t < T) {
+      half8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = tile[cc + e][tl];
+      *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = h;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    ob[c0 + threadIdx.x] = (half_t)0.f;
+    ob[(size_t)(T + 1) * Cp + c0 + threadIdx.x] = (half_t)0.f;
+  }
+}
+
 // h32[row] = E32[id[row]] + P32[pos0 + (row % L)]   (utils/load_model.py:645,668-673)
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E,
                                                      const float* __restrict__ P, float* __restrict__ h, int rows, int L,
@@ -251,6 +297,17 @@ extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T,
   dim3 grid((T + 63) / 64, Cp / 64, B);
   hipLaunchKernelGGL(signal_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
   NS_CHECK_LAUNCH("ns_signal_pack");
+  return NS_OK;
+}
+
+extern "C" int ns_feed_pack(const ns_feed_item* items_dev, int B, int ch, int T, int Cp, void* out16, float* x32,
+                            void* stream) {
+  NS_CHECK_ARG(items_dev && out16, "ns_feed_pack: null pointer");
+  NS_CHECK_ARG(B > 0 && B <= 65535 && ch > 0 && T > 0 && Cp >= ch && Cp % 64 == 0,
+               "ns_feed_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
+  dim3 grid((T + 63) / 64, Cp / 64, B);
+  hipLaunchKernelGGL(feed_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, items_dev, (half_t*)out16, x32, ch, T, Cp);
+  NS_CHECK_LAUNCH("ns_feed_pack");
   return NS_OK;
 }
 

@@ -27,6 +27,7 @@ from dataclasses import dataclass, field
 import torch
 
 from . import ops
+from .feed import PackedSignal
 from .lib import AdamWCfg
 from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN,
                   rowmap)
@@ -466,15 +467,21 @@ class MegWhisperEngine:
         dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
         B, T, S, Cp = b["B"], dims.T, dims.src_pos, dims.ch_pad
         M = B * S
-        assert x32.shape == (B, dims.ch, T) and x32.dtype == F32 and x32.is_contiguous()
-        ops.signal_pack(x32, b["xin"], B, dims.ch, T, Cp)
+        if isinstance(x32, PackedSignal):       # on-GPU feed: the batch arrives already packed (feed.py)
+            assert x32.shape == (B, dims.ch, T) and x32.xin.shape == (B, T + 2, Cp)
+            xin = x32.acquire().xin
+        else:
+            assert x32.shape == (B, dims.ch, T) and x32.dtype == F32 and x32.is_contiguous()
+            xin = b["xin"]
+            ops.signal_pack(x32, xin, B, dims.ch, T, Cp)
+        b["xin_cur"] = xin                      # the conv weight gradients read it again in backward
         c2 = self.conv_ops["conv2"]
         pb = lambda n: self.pview(f"model.encoder.{n}.bias")  # noqa: E731
         T2 = T // 2
         if self.frontend == "base":
             c0, c1 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"]
             # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
-            ops.gemm(A=b["xin"], am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
+            ops.gemm(A=xin, am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
                      bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d),
                      g16m=rowmap(d, T, (T + 2) * d), flags=GELU_FWD)
             # conv1.2 (k3,s2) + the encoder's outer GELU
@@ -484,7 +491,7 @@ class MegWhisperEngine:
         else:
             # 'replace': one stride-2 conv over the packed signal + the encoder's outer GELU
             cr = self.conv_ops["conv1"]
-            ops.gemm(A=b["xin"], am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
+            ops.gemm(A=xin, am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
                      bias=pb("conv1"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
                      g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
         # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
@@ -785,7 +792,7 @@ class MegWhisperEngine:
         hal1 = rowmap(d, T2, (T2 + 2) * d)
         if self.frontend == "replace":
             ops.colsum(b["dpre1"], gp("model.encoder.conv1.bias"), B * (T2 + 2), d, d)
-            self._wgrad(dp1, 0, b["xin"], 0, B * T2, d, 3 * Cp, "model.encoder.conv1.wp", am=hal1,
+            self._wgrad(dp1, 0, b["xin_cur"], 0, B * T2, d, 3 * Cp, "model.encoder.conv1.wp", am=hal1,
                         bm=rowmap(2 * Cp, T2, (T + 2) * Cp))
             return
         c1 = self.conv_ops["conv1.2"]
@@ -798,7 +805,7 @@ class MegWhisperEngine:
         ops.gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
                  P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         ops.colsum(b["dpre0"], gp("model.encoder.conv1.0.bias"), B * T, d, d)
-        self._wgrad(b["dpre0"], 0, b["xin"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
+        self._wgrad(b["dpre0"], 0, b["xin_cur"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
                     bm=rowmap(Cp, T, (T + 2) * Cp))
 
     # ------------------------------------------------------------------ optimizer

@@ -69,6 +69,14 @@ class AttnDesc(C.Structure):
     ]
 
 
+class FeedItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+NS_FEED_F64, NS_FEED_F32, NS_FEED_F16 = 0, 1, 2
+
+
 class AdamWCfg(C.Structure):
     _fields_ = [
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -131,6 +139,7 @@ SIGNATURES = {
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ns_feed_pack": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ns_embed_pos": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _i, _vp]),
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),

@@ -10,7 +10,7 @@ from . import lib as L
 from .lib import (AdamWCfg, AttnDesc, CastJob, GemmDesc, RowMap, NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A,
                   NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN)
 
-__all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pack", "embed_pos", "attn_fwd",
+__all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pack", "feed_pack", "embed_pos", "attn_fwd",
            "attn_bwd", "cross_entropy", "dgelu_mul", "colsum", "argmax_rows", "grad_norm", "adamw_step", "cast_jobs", "make_cast_jobs",
            "NS_GEMM_GELU", "NS_GEMM_DGELU", "NS_GEMM_TN", "NS_GEMM_ATOMIC32", "NS_GEMM_DROP_A", "NS_GEMM_GELU_SAVE_GRAD",
            "NS_GEMM_MUL_P16"]
@@ -94,6 +94,11 @@ def layernorm_bwd(dy, dy_is_f32, x32, mean, rstd, gamma, dres, dx32, dx16, rows,
 
 def signal_pack(x32, out16, B, ch, T, Cp):
     L.check(L.load().ns_signal_pack(ptr(x32), ptr(out16), B, ch, T, Cp, _stream()), "ns_signal_pack")
+
+
+def feed_pack(items_dev, B, ch, T, Cp, out16, x32=None):
+    """items_dev: device uint8/int64 tensor holding B ns_feed_item records (32 bytes each)"""
+    L.check(L.load().ns_feed_pack(ptr(items_dev), B, ch, T, Cp, ptr(out16), ptr(x32), _stream()), "ns_feed_pack")
 
 
 def embed_pos(ids, E32, P32, h32, rows, Lseq, d, pos0=0, pos0_dev=None):

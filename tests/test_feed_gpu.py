@@ -1,0 +1,82 @@
+"""ns_feed_pack + SignalFeed on the GPU: the packed fp16 batch and the optional fp32 tensor must be BIT-identical to
+the host path (reader -> collator -> ns_signal_pack), and a training step fed either way must give the same loss."""
+import numpy as np
+import pytest
+import torch
+
+from neuspeech1_amd.synthetic import SyntheticProcessor
+from neuspeech1_amd.weights import TINY, WHISPER_BASE, make_state_dict, synth_batch
+from tests.feed_cases import datasets, write_cases
+from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("modal_ch", [208, 273])
+def test_feed_pack_is_bit_identical_to_collator_plus_signal_pack(dev, tmp_path, modal_ch):
+    from neuspeech1_amd import ops
+    from neuspeech1_amd.feed import SignalFeed
+    proc = SyntheticProcessor(WHISPER_BASE)
+    jl = write_cases(str(tmp_path), modal_ch)
+    ds, ds_raw = datasets(jl, proc, modal_ch)
+    coll = DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+    ref = coll([ds[i] for i in range(len(ds))])
+    raws = coll([ds_raw[i] for i in range(len(ds_raw))])["input_features"]
+    B, T, Cp = len(raws), 6000, (modal_ch + 63) // 64 * 64
+    x32 = ref["input_features"].to(dev)
+    want = torch.full((B, T + 2, Cp), 7.0, dtype=torch.float16, device=dev)
+    ops.signal_pack(x32, want, B, modal_ch, T, Cp)
+    feed = SignalFeed(dev, modal_ch, T, Cp, threads=4, keep_x32=True)
+    for rep in range(3):        # slot reuse: the same staging blocks are refilled
+        ps = feed.load(raws).acquire()
+        torch.cuda.synchronize()
+        assert torch.equal(ps.xin, want)
+        assert torch.equal(ps.x32, x32)
+        ps.release()
+    assert len(feed.slots) <= 2
+    # a smaller batch in a reversed order through the same slot
+    ps = feed.submit(raws[::-1][:5]).result().acquire()      # through the loader thread
+    torch.cuda.synchronize()
+    assert torch.equal(ps.xin, want.flip(0)[:5])
+    # unreleased batches take new slots instead of overwriting live ones
+    ps2 = feed.load(raws[:2]).acquire()
+    torch.cuda.synchronize()
+    assert ps2.slot is not ps.slot and torch.equal(ps.xin, want.flip(0)[:5]) and torch.equal(ps2.xin, want[:2])
+    feed.close()
+
+
+def test_training_step_from_the_feed_matches_the_tensor_path(dev, tmp_path):
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    from neuspeech1_amd.feed import RawSignal, SignalFeed
+    dims = TINY
+    rng = np.random.default_rng(5)
+    raws, xs = [], []
+    for i, n in enumerate((dims.T, dims.T // 3, dims.T + 77, 40)):
+        a = rng.standard_normal((dims.ch + (i % 2) * 5, n))
+        p = str(tmp_path / f"r{i}.npy")
+        np.save(p, a)
+        raws.append(RawSignal(p, 0, dims.ch, dims.ch))
+        x = np.zeros((dims.ch, dims.T))
+        x[:, :min(n, dims.T)] = a[:dims.ch, :dims.T]
+        xs.append(x)
+    x32 = torch.from_numpy(np.stack(xs)).float().to(dev)
+    labels = torch.from_numpy(synth_batch(dims, 4, 77)[1]).to(dev)
+
+    def run(feed_it):
+        torch.manual_seed(3)
+        eng = MegWhisperEngine(dims, make_state_dict(dims, 42), lora=LoraSpec(r=8, alpha=16.0, dropout=0.0),
+                               train_cfg=TrainCfg(lr=1e-3, warmup_steps=2, total_steps=10), device=dev)
+        feed = SignalFeed(dev, dims.ch, dims.T, dims.ch_pad, threads=2) if feed_it else None
+        losses = []
+        for _ in range(3):
+            x = feed.load(raws) if feed_it else x32
+            losses.append(eng.train_step(x, labels).item())
+            if feed_it:
+                x.release()
+        torch.cuda.synchronize()
+        return losses, eng.P.clone()
+    la, pa = run(False)
+    lb, pb = run(True)
+    # identical operands -> identical kernels; only the fp32 atomics of the weight gradients reorder
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+    assert (pa - pb).abs().max().item() < 5e-4

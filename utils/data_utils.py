@@ -55,11 +55,15 @@ class DataCollatorSpeechSeq2SeqWithPadding:
 
     def __call__(self, features: List[Dict[str, Union[List[int], torch.Tensor]]]) -> Dict[str, torch.Tensor]:
         # one pinned float32 block; each sample is converted (f64 -> f32) straight into its slot
-        first = np.asarray(features[0]["input_features"][0])
-        x = torch.empty((len(features),) + first.shape, dtype=torch.float32)
-        for i, f in enumerate(features):
-            x[i] = torch.from_numpy(np.ascontiguousarray(f["input_features"][0]))
-        batch = {"input_features": x}
+        if type(features[0]["input_features"][0]).__name__ == "RawSignal":
+            # on-GPU feed (CustomDataset(raw_signals=True)): the recordings are described, not loaded
+            batch = {"input_features": [f["input_features"][0] for f in features]}
+        else:
+            first = np.asarray(features[0]["input_features"][0])
+            x = torch.empty((len(features),) + first.shape, dtype=torch.float32)
+            for i, f in enumerate(features):
+                x[i] = torch.from_numpy(np.ascontiguousarray(f["input_features"][0]))
+            batch = {"input_features": x}
         tok = self.processor.tokenizer
         label_features = [{"input_ids": f["labels"]} for f in features]
         labels_batch = tok.pad(label_features, return_tensors="pt")

@@ -29,7 +29,7 @@ class CustomDataset(Dataset):
     def __init__(self, data_list_path, processor, data_list_dir="", mode="train", modal="eeg", modal_ch=66,
                  level="sentences", language=None, filter_dataset=False, timestamps=False, sample_rate=200,
                  orig_sample_rate=200, min_duration=0.5, max_duration=30, combine_sentences=False,
-                 split_sentences=False, subj=None, augment_config_path=None):
+                 split_sentences=False, subj=None, augment_config_path=None, raw_signals=False):
         assert min_duration >= 0.5, f"min_duration must be >= 0.5, got {min_duration}"
         assert max_duration <= 30, f"max_duration must be <= 30, got {max_duration}"
         if modal != "eeg":
@@ -43,6 +43,9 @@ class CustomDataset(Dataset):
         self.language, self.filter_dataset, self.timestamps = language, filter_dataset, timestamps
         self.data_list_dir, self.modal, self.modal_ch = data_list_dir, modal, modal_ch
         self.min_duration, self.max_duration, self.subj = min_duration, max_duration, subj
+        # raw_signals (addition of this build): __getitem__ returns a neuspeech1_amd.feed.RawSignal (file + channel
+        # slice) instead of the loaded array; the slice / pad / crop / cast rules below then run on the GPU (ns_feed_pack)
+        self.raw_signals = raw_signals
         vocab = processor.tokenizer.get_vocab()
         self.startoftranscript = vocab["<|startoftranscript|>"]
         self.endoftext = vocab["<|endoftext|>"]
@@ -71,16 +74,22 @@ class CustomDataset(Dataset):
         row = copy.deepcopy(self.data_list[idx])
         path = row[self.modal]["path"]
         assert path is not None
-        sample = np.load(path)                       # (>=ch, n) float64
-        if "schoffelen" in path:
-            sample = sample[28:301]
-        elif "gwilliams" in path:
-            sample = sample[:208]
-        else:
-            sample = sample[: self.modal_ch]
+        lo, hi = self.channel_slice(path)
+        if self.raw_signals:
+            from neuspeech1_amd.feed import RawSignal
+            return RawSignal(path, lo, hi, self.modal_ch), self.signal_sample_rate, row["sentence"], row.get("language")
+        sample = np.load(path)[lo:hi]                # (>=ch, n) float64
         if self.modal_ch > sample.shape[0]:
             sample = self.pad_sample_ch(sample)
         return sample, self.signal_sample_rate, row["sentence"], row.get("language")
+
+    def channel_slice(self, path):
+        """dataset-specific channel rows (reference :282-290)"""
+        if "schoffelen" in path:
+            return 28, 301
+        if "gwilliams" in path:
+            return 0, 208
+        return 0, self.modal_ch
 
     def __getitem__(self, idx):
         sample, _, transcript, language = self._get_list_data(idx)
@@ -92,6 +101,8 @@ class CustomDataset(Dataset):
 
     def padding_sample(self, sample):
         """crop to max_duration*sample_rate samples, zero-pad on the right (reference :496-506)."""
+        if self.raw_signals:
+            return [sample]
         max_length = int(self.max_duration * self.signal_sample_rate)
         sample = sample[:, :max_length]
         sample = np.pad(sample, pad_width=((0, 0), (0, max_length - sample.shape[-1])))
