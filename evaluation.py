@@ -55,6 +55,7 @@ def build_parser():
     # additions of this build
     add_arg("num_beams", type=int, default=5, help="beam width (reference: 5)")
     add_arg("max_new_tokens", type=int, default=None, help="cap on generated tokens")
+    add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack)")
     return parser
 
 
@@ -93,14 +94,32 @@ def main(argv=None):
     base = (f'formal_test_results{"_" + args.extra_name if args.extra_name is not None else ""}'
             f'{"no_post_processing" if not args.post_processing else "post_processing"}'
             f'{"_noise" if args.noise else ""}{"_tf" if args.teacher_forcing else ""}')
+    feed = None
+    if args.device_feed and not args.noise and model.device.type == "cuda":
+        # recordings go to the GPU as bytes; slice / pad / crop / cast run there (neuspeech1_amd/feed.py)
+        from neuspeech1_amd.feed import SignalFeed
+        dims = model.engine().dims
+        test_dataset.raw_signals = True
+        feed = SignalFeed(model.device, dims.ch, dims.T, dims.ch_pad, threads=max(2, args.num_workers))
+
+    def batches():
+        """(input, labels) with the NEXT batch's file reads already running on the feed's loader thread"""
+        it = iter(loader)
+        stage = lambda b: feed.submit(b["input_features"]) if (feed is not None and b is not None) else None  # noqa: E731
+        nxt = next(it, None)
+        fut = stage(nxt)
+        while nxt is not None:
+            cur, cur_fut = nxt, fut
+            nxt = next(it, None)
+            fut = stage(nxt)
+            yield (cur_fut.result() if cur_fut is not None else cur["input_features"].to(model.device)), cur["labels"]
+
     preds, refs = [], []
     n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
     with open(os.path.join(out_dir, base + ".txt"), "w") as f, torch.no_grad():
-        for batch in loader:
-            x = batch["input_features"].to(model.device)
+        for x, labels in batches():
             if args.noise:
                 x = torch.randn_like(x)
-            labels = batch["labels"]
             if not args.teacher_forcing:
                 kw = {}
                 if args.language.lower() != "english":
@@ -118,6 +137,8 @@ def main(argv=None):
                 n_match += int(((gen[:, :-1] == labels[:, 1:]) & ~ign[:, 1:]).sum())
                 n_lab += int((~ign[:, 1:]).sum())
                 gen = gen.masked_fill(ign, -100).numpy()
+            if hasattr(x, "release"):
+                x.release()
             lab = np.where(labels.numpy() != -100, labels.numpy(), processor.tokenizer.pad_token_id)
             dp = processor.batch_decode(gen, skip_special_tokens=True)
             dl = processor.batch_decode(lab, skip_special_tokens=True)

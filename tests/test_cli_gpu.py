@@ -61,6 +61,10 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
     finally:
         os.chdir(cwd)
     assert hyp_merged == hyp_adapter
+    # the host reader + collator path (--device_feed=False) decodes the same hypotheses as the on-GPU feed (default)
+    evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                     "--max_new_tokens=8", "--device_feed=False"] + common)
+    assert open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).read() == hyp_adapter
 
 
 def test_finetune_first_layer_only_with_gradient_accumulation(dev, tmp_path):
