@@ -117,7 +117,8 @@ typedef struct {
 } ns_gemm_desc;
 
 int ns_gemm(const ns_gemm_desc* d, void* stream);
-/* A/B knob for benchmarks: 1 (default) = LDS-DMA ring kernel for the wide NT form, 0 = register-staged kernel */
+/* A/B knob for benchmarks: 1 (default) = automatic kernel choice, 0 = register-staged kernel only; 2..5 force one of
+ * the wide NT kernels (see ns_gemm.hip), 6 = automatic without the small-M split-K kernel */
 void ns_debug_set_ring(int on);
 
 /* ------------------------------------------------------------------------

@@ -355,6 +355,8 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
+int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
+bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -409,6 +411,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   } else if (tn) {
     dim3 grid(tiles, 1, d->splits);
     if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
+  } else if (g_use_ring != 6 && g_use_ring != 0 && ns_gemm_smallm_ok(d)) {
+    ns_gemm_smallm_launch(d, st);   // decode shapes: 32x32 tiles, K split over the four waves (mode 6 = off, for A/B runs)
   } else if (skinny) {
     if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {

@@ -52,6 +52,42 @@ def test_gemm_nt_bias(ops, dev, M, N, K):
     close(Cout, ref, 2e-3 * math.sqrt(K / 64), 2e-3, "gemm_nt")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 512, 512), (128, 2048, 512), (128, 512, 2048), (640, 512, 528), (5, 520, 272),
+                                   (33, 1284, 1280)])
+def test_gemm_small_m_split_k_kernel(ops, dev, M, N, K):
+    """decode shapes take the 32x32 split-K kernel (ns_gemm_smallm.hip): same results as the staged 128x32 tile
+    (ns_debug_set_ring(6)) up to fp32 summation order, ragged M / N / K tails, GELU + in-place residual epilogues;
+    integer data must come out exact through both"""
+    from neuspeech1_amd import lib
+    A, B = rnd((M, K), dev, 1.0, seed=1), rnd((N, K), dev, 0.05, seed=2)
+    bias = rnd((N,), dev, 0.5, torch.float32, seed=3)
+    R = rnd((M, N), dev, 1.0, torch.float32, seed=4)
+    res = {}
+    try:
+        for mode in (6, 1):
+            lib.load().ns_debug_set_ring(mode)
+            C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+            Gl = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+            H = R.clone()
+            ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=C, c16m=ops.rowmap(N), G16=Gl,
+                     g16m=ops.rowmap(N), flags=ops.NS_GEMM_GELU)
+            ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, R32=H, H32=H, h32m=ops.rowmap(N))
+            Ai = ((torch.arange(M * K, device=dev).reshape(M, K) * 7 + 3) % 5 - 2).half()
+            Bi = ((torch.arange(N * K, device=dev).reshape(N, K) * 11 + 1) % 7 - 3).half()
+            Ci = torch.zeros(M, N, device=dev, dtype=torch.float32)
+            ops.gemm(A=Ai, am=ops.rowmap(K), K=K, B=Bi, ldb=K, M=M, N=N, C32=Ci, ldc32=N)
+            assert torch.equal(Ci, Ai.float() @ Bi.float().T)
+            res[mode] = (C, Gl, H)
+    finally:
+        lib.load().ns_debug_set_ring(1)
+    ref = A.float() @ B.float().T + bias
+    tol = 2e-3 * math.sqrt(K / 64)
+    close(res[1][0], ref, tol, 2e-3, "C16")
+    close(res[1][1], F.gelu(res[1][0].float()), 1e-3, 1e-3, "G16")
+    close(res[1][2], R + ref.half().float(), 2 * tol, 2e-3, "H32 in place")
+    close(res[1][0], res[6][0].float(), 2e-3, 2e-3, "small-M vs staged tile")
+
+
 def test_gemm_epilogues(ops, dev):
     M, N, K, S = 384, 256, 128, 96
     A, B = rnd((M, K), dev, seed=1), rnd((N, K), dev, 0.1, seed=2)
@@ -391,3 +427,42 @@ def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
                  flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=3, drop_p=p, drop_seed=seed)
         close(dA, du.float().T @ (x.float() * keep), 3e-2, 3e-3, f"dropout wgrad (ring mode {mode})")
     lib.load().ns_debug_set_ring(1)
+
+
+@pytest.mark.parametrize("nq,Lk", [(1, 1500), (1, 7), (5, 1500), (3, 130), (8, 33)])
+def test_attn_decode_cross_layout(ops, dev, nq, Lk):
+    """ns_attn_decode on a per-group K/V block (cross-attention layout): nq query rows of a group share its Lk keys;
+    against fp32 softmax(QK^T)V (the kernel takes pre-scaled queries)."""
+    groups, H, d = 6, 4, 64
+    Q = rnd((groups * nq, H * d), dev, 0.6, seed=1)
+    KV = rnd((groups * Lk, 2 * H * d), dev, 0.7, seed=2)
+    O = torch.full((groups * nq, H * d), float("nan"), device=dev, dtype=torch.float16)
+    ops.attn_decode(Q=Q, K=KV, V=(KV, H * d), O=O, groups=groups, nq=nq, H=H, Lk=Lk, Lk_max=Lk, ldq=H * d, ldk=2 * H * d,
+                    ldv=2 * H * d, ldo=H * d, kv_group_stride=Lk)
+    q = Q.float().view(groups, nq, H, d).transpose(1, 2)
+    k = KV.float()[:, :H * d].view(groups, Lk, H, d).transpose(1, 2)
+    v = KV.float()[:, H * d:].view(groups, Lk, H, d).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(groups * nq, H * d)
+    close(O, ref, 2e-3, 2e-3, "attn_decode")
+
+
+@pytest.mark.parametrize("Lk", [1, 9, 68])
+def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk):
+    """self-attention over the position-major K/V cache: row r at position j reads cache row anc[r][j] (beam ancestry),
+    the live length comes from device memory."""
+    rows, H, d, Lmax = 10, 4, 64, 80
+    Q = rnd((rows, 3 * H * d), dev, 0.6, seed=3)
+    cache = rnd((Lmax * rows, 2 * H * d), dev, 0.7, seed=4)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    anc = torch.randint(0, rows, (rows, Lmax), generator=g, dtype=torch.int32).to(dev)
+    O = torch.full((rows, H * d), float("nan"), device=dev, dtype=torch.float16)
+    klen = torch.tensor([Lk], device=dev, dtype=torch.int32)
+    ops.attn_decode(Q=Q, K=cache, V=(cache, H * d), O=O, groups=rows, nq=1, H=H, Lk=Lmax, Lk_max=Lmax, ldq=3 * H * d,
+                    ldk=2 * H * d, ldv=2 * H * d, ldo=H * d, anc=anc, anc_ld=Lmax, kv_pos_stride=rows, kv_len_dev=klen)
+    c = cache.float().view(Lmax, rows, 2, H, d)
+    idx = anc[:, :Lk].long()                                               # (rows, Lk)
+    kv = c[torch.arange(Lk, device=dev).unsqueeze(0), idx]                 # (rows, Lk, 2, H, d)
+    q = Q.float()[:, :H * d].view(rows, H, 1, d)
+    k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).reshape(rows, H * d)
+    close(O, ref, 2e-3, 2e-3, "attn_decode anc")
