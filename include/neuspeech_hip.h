@@ -273,6 +273,22 @@ typedef struct {
 } ns_attn_decode_desc;
 int ns_attn_decode(const ns_attn_decode_desc* d, void* stream);
 
+/* Cross-attention of a FEW query rows (nq <= 16: the beams of one sequence, or the single greedy row) against the
+ * sequence's long encoder K/V, on the matrix cores and without LDS staging: the four waves of a workgroup split the
+ * keys, load K rows and rows of the TRANSPOSED value image straight into MFMA fragments, keep their own online-softmax
+ * state and meet once at the end.  The K/V of a sequence is written once per utterance and read at every decode step
+ * (evaluation.py:369-386 -> utils/load_model.py:1332-1351 keeps the cross K/V in the cache), so the value image is
+ * stored transposed once by ns_vt_pack: element (group g, head h, dim d, key j) at ((g*H + h)*64 + d)*ldvt + j,
+ * ldvt % 32 == 0, ldvt >= Lk, columns [Lk, ldvt) zero.  Key row of K: g*Lk + j (row stride ldk).  Queries pre-scaled. */
+typedef struct {
+  const void *Q, *K, *Vt; void* O;
+  int32_t groups, nq, H, Lk;
+  int32_t ldq, ldk, ldvt, ldo;
+} ns_attn_fewq_desc;
+int ns_attn_fewq(const ns_attn_fewq_desc* d, void* stream);
+/* V (fp16 rows g*Lk + j, row stride ldv, head h at columns h*64..) -> the transposed image described above */
+int ns_vt_pack(const void* v16, int ldv, void* vt16, int groups, int H, int Lk, int ldvt, void* stream);
+
 /* Last-position logits (fp16, rows x ldv) -> processed fp32 scores (rows x V):
  * [log_softmax] -> repetition penalty (s<0 ? s*p : s/p on tokens already in ids[row][0:cur_len]) ->
  * no-repeat-ngram (-inf) -> suppress / begin-suppress lists (-inf) -> + beam_scores[row].

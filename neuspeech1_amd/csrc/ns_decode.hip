@@ -132,6 +132,157 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
   }
 }
 
+// ---------------------------------------------------------------------------------------------- few-query attention
+// See ns_attn_fewq in the header.  v_mfma_f32_16x16x32_f16(X, Y, C): lane (l & 15, l >> 4) of X holds row l & 15,
+// k = 8 (l >> 4) .. +7; of Y column l & 15, same k; C[row 4 (l >> 4) + i][column l & 15].
+//   S^T[key][q] = K Q^T      X = K rows (row r of the tile is key k0 + 8 (r >> 2) + 4 t + (r & 3), t = tile 0 / 1),
+//                            Y = Q rows  ->  lane (q, g) holds the scores of keys k0 + 8 g + 4 t + i: 8 CONSECUTIVE keys
+//   O^T[d][q]   = V^T P^T    X = rows of the transposed value image (one 16-B load: keys k0 + 8 g .. + 7 of dim d),
+//                            Y = those 8 probabilities, already in place  ->  the query index of a lane is l & 15 in
+//                            both products, so max / sum / rescale are lane-local plus two cross-lane steps.
+typedef float fq_f32x4 __attribute__((ext_vector_type(4)));
+struct fq_frags { half8 k[2][2]; half8 v[4]; };   // k[tile][k32 half], v[dim tile]
+
+__global__ __launch_bounds__(256) void attn_fewq_kernel(const ns_attn_fewq_desc p) {
+  __shared__ float red[4][16][D + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int grp = blockIdx.x, h = blockIdx.y, Lk = p.Lk;
+  half8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (half_t)0.f;
+  half8 qf[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+    qf[hh] = lr < p.nq ? *(const half8*)((const half_t*)p.Q + (long long)(grp * p.nq + lr) * p.ldq + h * D + 32 * hh + 8 * lg)
+                       : zero8;
+  const half_t* Kg = (const half_t*)p.K + (long long)grp * Lk * p.ldk + h * D + 8 * lg;
+  const half_t* Vg = (const half_t*)p.Vt + ((long long)(grp * p.H + h) * D + lr) * p.ldvt + 8 * lg;
+  const int krow0 = 8 * (lr >> 2) + (lr & 3);
+  const int chunk = (((Lk + 3) >> 2) + 31) & ~31;
+  const int k_begin = wave * chunk, k_end = min(Lk, k_begin + chunk);
+
+  auto load = [&](int k0, fq_frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long long ro = (long long)min(k0 + krow0 + 4 * t, Lk - 1) * p.ldk;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) f.k[t][hh] = *(const half8*)(Kg + ro + 32 * hh);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) f.v[dt] = *(const half8*)(Vg + (long long)16 * dt * p.ldvt + k0);
+  };
+
+  float m = -INFINITY, l = 0.f;
+  fq_f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = fq_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto tile = [&](int k0, const fq_frags& f) __attribute__((always_inline)) {
+    fq_f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = fq_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.k[t][hh], qf[hh], s[t], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (k0 + 8 * lg + 4 * t + i >= Lk) s[t][i] = -INFINITY;
+        mx = fmaxf(mx, s[t][i]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));     // key k0 < Lk exists: finite
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    half8 pf;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = __expf(s[t][i] - mn);
+        ps += e;
+        pf[4 * t + i] = (half_t)e;
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      o[dt] *= alpha;
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.v[dt], pf, o[dt], 0, 0, 0);
+    }
+  };
+
+  // three fragment stages, loads two 32-key tiles ahead
+  fq_frags f[3];
+  if (k_begin < k_end) load(k_begin, f[0]);
+  if (k_begin + 32 < k_end) load(k_begin + 32, f[1]);
+  for (int k0 = k_begin; k0 < k_end; k0 += 96) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int kk = k0 + 32 * u;
+      if (kk + 64 < k_end) load(kk + 64, f[(u + 2) % 3]);
+      if (kk < k_end) tile(kk, f[u]);
+    }
+  }
+  // o[dt][i] = O^T[16 dt + 4 lg + i][q = lr] of this wave's keys
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][lr][16 * dt + 4 * lg + i] = o[dt][i];
+  if (lg == 0) { red[wave][lr][D] = m; red[wave][lr][D + 1] = l; }
+  __syncthreads();
+  for (int idx = tid; idx < p.nq * D; idx += 256) {
+    const int qi = idx >> 6, dd = idx & 63;
+    float M = red[0][qi][D];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, red[w][qi][D]);
+    float v = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = red[w][qi][D];
+      const float sc = mw == -INFINITY ? 0.f : __expf(mw - M);
+      v += red[w][qi][dd] * sc;
+      L += red[w][qi][D + 1] * sc;
+    }
+    ((half_t*)p.O)[(long long)(grp * p.nq + qi) * p.ldo + h * D + dd] = (half_t)(v / L);
+  }
+}
+
+// V rows (key-major) -> transposed value image; 64 keys x 64 dims per workgroup through an LDS tile
+__global__ __launch_bounds__(256) void vt_pack_kernel(const half_t* __restrict__ v, int ldv, half_t* __restrict__ vt, int H,
+                                                       int Lk, int ldvt) {
+  __shared__ half_t tile[64][D + 2];
+  const int j0 = blockIdx.x * 64, h = blockIdx.y, g = blockIdx.z;
+  const int c8 = (threadIdx.x & 7) * 8, r = threadIdx.x >> 3;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int j = j0 + r + 32 * it;
+    half8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (half_t)0.f;
+    if (j < Lk) x = *(const half8*)(v + ((long long)g * Lk + j) * ldv + h * D + c8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r + 32 * it][c8 + e] = x[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int dd = r + 32 * it;
+    if (j0 + c8 < ldvt) {
+      half8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[c8 + e][dd];
+      *(half8*)(vt + ((long long)(g * H + h) * D + dd) * ldvt + j0 + c8) = x;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- processors
 __device__ __forceinline__ float blk_reduce(float v, bool is_max, float* sh) {
   v = is_max ? ns_wave_max(v) : ns_wave_sum(v);
@@ -595,6 +746,26 @@ extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
   }
 #undef NS_AD
   NS_CHECK_LAUNCH("ns_attn_decode");
+  return NS_OK;
+}
+
+extern "C" int ns_attn_fewq(const ns_attn_fewq_desc* d, void* stream) {
+  NS_CHECK_ARG(d && d->Q && d->K && d->Vt && d->O, "ns_attn_fewq: null pointer");
+  NS_CHECK_ARG(d->nq >= 1 && d->nq <= 16 && d->groups > 0 && d->H > 0 && d->Lk > 0, "ns_attn_fewq: bad shape nq=%d groups=%d Lk=%d",
+               d->nq, d->groups, d->Lk);
+  NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 32 == 0 && d->ldvt >= d->Lk,
+               "ns_attn_fewq: ldq / ldk must be multiples of 8, ldvt a multiple of 32 and >= Lk");
+  hipLaunchKernelGGL(attn_fewq_kernel, dim3(d->groups, d->H), dim3(256), 0, (hipStream_t)stream, *d);
+  NS_CHECK_LAUNCH("ns_attn_fewq");
+  return NS_OK;
+}
+
+extern "C" int ns_vt_pack(const void* v16, int ldv, void* vt16, int groups, int H, int Lk, int ldvt, void* stream) {
+  NS_CHECK_ARG(v16 && vt16 && groups > 0 && groups <= 65535 && H > 0 && Lk > 0, "ns_vt_pack: bad arguments");
+  NS_CHECK_ARG(ldv % 8 == 0 && ldvt % 32 == 0 && ldvt >= Lk, "ns_vt_pack: ldv must be a multiple of 8, ldvt of 32 and >= Lk");
+  hipLaunchKernelGGL(vt_pack_kernel, dim3((ldvt + 63) / 64, H, groups), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)v16, ldv, (half_t*)vt16, H, Lk, ldvt);
+  NS_CHECK_LAUNCH("ns_vt_pack");
   return NS_OK;
 }
 

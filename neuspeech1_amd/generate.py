@@ -23,9 +23,10 @@ F16, F32 = torch.float16, torch.float32
 
 
 class Generator:
-    def __init__(self, engine, use_graph: bool = True, graph_min_steps: int = 24):
+    def __init__(self, engine, use_graph: bool = True, graph_min_steps: int = 24, cross_mfma: bool = True):
         self.eng = engine
         self.use_graph = use_graph
+        self.cross_mfma = cross_mfma    # beam cross-attention through ns_attn_fewq (False: the flash kernel)
         # capturing the four graphs costs ~3-4 ms; measured on MI355X the decode loop is GPU-bound (B=128: replay and
         # eager launches give the same tokens/s), so graphs only insure against a slow / contended host and are
         # skipped for short generations
@@ -52,11 +53,22 @@ class Generator:
         eng._b = b
         enc16 = eng.encode(x32.contiguous(), b, False)
         M = B * S
-        kvx = []
+        kvx, vtx = [], []
+        Sp = (S + 31) // 32 * 32
+        # beams of a sequence = the few query rows of ns_attn_fewq (75 k tokens/s at beam 5, B = 128, against 71 k with
+        # the 128-row flash kernel and 64 k with the per-key VALU kernel); the single greedy row stays on
+        # ns_attn_decode (same speed, no transposed copy)
+        fewq = self.cross_mfma and 1 < nb <= 16
         for Lw in eng.dec:
             t = torch.empty(M, 2 * d, device=dev, dtype=F16)
             eng._lin(enc16, M, Lw["ckv"], C16=t)
             kvx.append(t)
+            if fewq:
+                # the cross V of a sequence is written once and read at every step: keep it transposed so the value
+                # product's MFMA operand is one 16-B load per lane (ns_attn_fewq)
+                vt = torch.empty(B, H, 64, Sp, device=dev, dtype=F16)
+                ops.vt_pack((t, d), 2 * d, vt, B, H, S, Sp)
+                vtx.append(vt)
         # ---- decode state
         nl = dims.dec_layers
         kvc = [torch.zeros(max_len * Bp, 2 * d, device=dev, dtype=F16) for _ in range(nl)]
@@ -95,7 +107,10 @@ class Generator:
                 eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
                 ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["cq"], C16=qc)
-                if nb > 1:
+                if fewq:
+                    ops.attn_fewq(Q=qc, K=kvx[li], Vt=vtx[li], O=ao, groups=B, nq=nb, H=H, Lk=S, ldq=d, ldk=2 * d,
+                                  ldvt=Sp, ldo=d)
+                elif nb > 1:
                     # beams of a sequence = the "queries" of one flash-attention problem over the sequence's encoder
                     # K/V: the MFMA kernel reads the 384 KB per (sequence, head) once and is HBM-bound (~60 us / layer
                     # at B = 128), where the per-key VALU dot products of ns_attn_decode took 108 us at 5 beams

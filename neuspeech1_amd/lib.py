@@ -97,6 +97,12 @@ class AttnDecodeDesc(C.Structure):
     ]
 
 
+class AttnFewqDesc(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+                ("groups", C.c_int32), ("nq", C.c_int32), ("H", C.c_int32), ("Lk", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32)]
+
+
 class LogitsProcDesc(C.Structure):
     _fields_ = [
         ("logits16", C.c_void_p), ("scores32", C.c_void_p), ("ids", C.c_void_p), ("beam_scores", C.c_void_p),
@@ -151,6 +157,8 @@ SIGNATURES = {
     "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ns_argmax_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "ns_attn_decode": (C.c_int, [C.POINTER(AttnDecodeDesc), _vp]),
+    "ns_attn_fewq": (C.c_int, [C.POINTER(AttnFewqDesc), _vp]),
+    "ns_vt_pack": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "ns_logits_process": (C.c_int, [C.POINTER(LogitsProcDesc), _vp]),
     "ns_topk_workspace_bytes": (C.c_size_t, [_i, C.c_longlong, _i]),
     "ns_topk_groups": (C.c_int, [_vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),

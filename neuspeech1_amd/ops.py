@@ -186,6 +186,17 @@ def attn_decode(*, Q, K, V, O, groups, nq, H, Lk, Lk_max, ldq, ldk, ldv, ldo, an
     L.check(L.load().ns_attn_decode(C.byref(d), _stream()), "ns_attn_decode")
 
 
+def attn_fewq(*, Q, K, Vt, O, groups, nq, H, Lk, ldq, ldk, ldvt, ldo):
+    d = L.AttnFewqDesc()
+    d.Q, d.K, d.Vt, d.O = ptr(Q), ptr(K), ptr(Vt), ptr(O)
+    d.groups, d.nq, d.H, d.Lk, d.ldq, d.ldk, d.ldvt, d.ldo = groups, nq, H, Lk, ldq, ldk, ldvt, ldo
+    L.check(L.load().ns_attn_fewq(C.byref(d), _stream()), "ns_attn_fewq")
+
+
+def vt_pack(v16, ldv, vt16, groups, H, Lk, ldvt):
+    L.check(L.load().ns_vt_pack(ptr(v16), ldv, ptr(vt16), groups, H, Lk, ldvt, _stream()), "ns_vt_pack")
+
+
 def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, beam_scores=None,
                    repetition_penalty=1.0, no_repeat_ngram=0, suppress=None, n_suppress=0, begin_suppress=None,
                    n_begin_suppress=0, cur_len_dev=None):

@@ -466,3 +466,28 @@ def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk):
     k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
     ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).reshape(rows, H * d)
     close(O, ref, 2e-3, 2e-3, "attn_decode anc")
+
+
+@pytest.mark.parametrize("nq,Lk", [(5, 1500), (1, 1500), (16, 97), (3, 31), (8, 128), (2, 1)])
+def test_attn_fewq_and_vt_pack(ops, dev, nq, Lk):
+    """ns_vt_pack + ns_attn_fewq (few query rows against a long per-group K/V, MFMA, transposed value image) against
+    fp32 softmax(QK^T)V and against ns_attn_decode on the same operands."""
+    groups, H, d = 5, 4, 64
+    Q = rnd((groups * nq, H * d), dev, 0.6, seed=1)
+    KV = rnd((groups * Lk, 2 * H * d), dev, 0.7, seed=2)
+    ldvt = (Lk + 31) // 32 * 32
+    Vt = torch.full((groups, H, d, ldvt), float("nan"), device=dev, dtype=torch.float16)
+    ops.vt_pack((KV, H * d), 2 * H * d, Vt, groups, H, Lk, ldvt)
+    v = KV[:, H * d:].view(groups, Lk, H, d)
+    assert torch.equal(Vt[..., :Lk], v.permute(0, 2, 3, 1)) and (Vt[..., Lk:] == 0).all()
+    O = torch.full((groups * nq, H * d), float("nan"), device=dev, dtype=torch.float16)
+    ops.attn_fewq(Q=Q, K=KV, Vt=Vt, O=O, groups=groups, nq=nq, H=H, Lk=Lk, ldq=H * d, ldk=2 * H * d, ldvt=ldvt, ldo=H * d)
+    q = Q.float().view(groups, nq, H, d).transpose(1, 2)
+    k = KV.float()[:, :H * d].view(groups, Lk, H, d).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v.float().transpose(1, 2)).transpose(1, 2).reshape(groups * nq, H * d)
+    close(O, ref, 3e-3, 3e-3, "attn_fewq")
+    if nq <= 8:
+        O2 = torch.empty_like(O)
+        ops.attn_decode(Q=Q, K=KV, V=(KV, H * d), O=O2, groups=groups, nq=nq, H=H, Lk=Lk, Lk_max=Lk, ldq=H * d,
+                        ldk=2 * H * d, ldv=2 * H * d, ldo=H * d, kv_group_stride=Lk)
+        close(O, O2.float(), 3e-3, 3e-3, "attn_fewq vs attn_decode")
