@@ -270,6 +270,10 @@ def main(argv=None):
     if args.max_steps > 0:
         total_steps = min(total_steps, args.max_steps)
     whisper = model.model
+    if not args.fp16 and rank == 0:
+        print("note: the HIP path always computes the GEMM / attention operands in fp16 with fp32 accumulation and an fp32 "
+              "residual stream (what --fp16=True gives the reference); --fp16=False only switches the dynamic loss scaler "
+              "off.  Every recipe of the reference trains with --fp16=True.")
     whisper.train_cfg = TrainCfg(lr=args.learning_rate, warmup_steps=args.warmup_steps, total_steps=total_steps,
                                  fp16_scaler=args.fp16)
     whisper.config.use_cache = False
