@@ -179,9 +179,6 @@ def main(argv=None):
     print_arguments(args)
     if args.gradient_accumulation_steps < 1:
         raise ValueError("gradient_accumulation_steps must be >= 1")
-    if args.ft_full:
-        raise NotImplementedError("--ft_full (adapters on the decoder too) is outside the hot path: the engine adapts "
-                                  "encoder layers only (all of them, or the first --fine_tune_layers)")
     processor = get_processor(args.base_model, args.language, args.task, args.timestamps, args.local_files_only)
     ds_kw = dict(processor=processor, modal=args.modal, modal_ch=args.eeg_ch, sample_rate=args.sampling_rate,
                  orig_sample_rate=args.orig_sample_rate, language=args.language, filter_dataset=args.filter_dataset,
@@ -237,6 +234,8 @@ def main(argv=None):
     else:
         if args.fine_tune_layers is not None:
             prefixes = [f"model.encoder.layers.{i}." for i in range(args.fine_tune_layers)]
+        elif args.ft_full:
+            prefixes = ["model"]
         else:
             prefixes = ["model.encoder"]
         suffixes = ["k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2"]

@@ -50,6 +50,7 @@ class LoraSpec:
     adalora: bool = False
     orth_reg_weight: float = 0.5
     layers: int | None = None     # adapt only encoder layers 0 .. layers-1 (finetune.py --fine_tune_layers, :188-190)
+    decoder: bool = False         # --ft_full (finetune.py:191-192): adapters on every decoder projection too
 
     @property
     def scale(self) -> float:
@@ -75,6 +76,18 @@ class TrainCfg:
     growth_factor: float = 2.0
     backoff_factor: float = 0.5
     growth_interval: int = 2000
+
+
+# decoder adapter sites of one layer (--ft_full): (site, engine linear, projection names of the stacked groups,
+# input width is d except fc2, output width per group, rows = encoder rows for the cross K/V)
+def _dec_sites(d, f):
+    return (("self_attn.qkv", "qkv", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), d, d, False),
+            ("self_attn.out_proj", "out", ("self_attn.out_proj",), d, d, False),
+            ("encoder_attn.q_proj", "cq", ("encoder_attn.q_proj",), d, d, False),
+            ("encoder_attn.kv", "ckv", ("encoder_attn.k_proj", "encoder_attn.v_proj"), d, d, True),
+            ("encoder_attn.out_proj", "cout", ("encoder_attn.out_proj",), d, d, False),
+            ("fc1", "fc1", ("fc1",), d, f, False),
+            ("fc2", "fc2", ("fc2",), f, d, False))
 
 
 class _Lin:
@@ -116,6 +129,9 @@ class MegWhisperEngine:
         # ONE stride-2 conv `encoder.conv1` straight from the MEG channels
         self.frontend = "replace" if ("model.encoder.conv1.weight" in sd and "model.encoder.conv1.0.weight" not in sd) else "base"
         self.n_lora = 0 if not lora else (dims.enc_layers if lora.layers is None else int(lora.layers))
+        self.dec_lora = bool(lora and lora.decoder)
+        if self.dec_lora and self.n_lora != dims.enc_layers:
+            raise ValueError("LoraSpec.decoder (--ft_full) adapts the whole model: it excludes LoraSpec.layers")
         if lora and not 1 <= self.n_lora <= dims.enc_layers:
             raise ValueError(f"LoraSpec.layers={lora.layers} outside 1..{dims.enc_layers}")
         # ---------------- frozen operand packs
@@ -181,6 +197,15 @@ class MegWhisperEngine:
         Cp = dims.ch_pad
         segs = []  # (name, numel)
         self.lora_names = []
+        if self.dec_lora:       # the decoder's backward runs first: its adapter gradients are final first
+            for i in reversed(range(dims.dec_layers)):
+                p = f"model.decoder.layers.{i}."
+                for site, _, projs, kin, nout, _ in _dec_sites(d, f):
+                    G = len(projs)
+                    segs.append((p + site + ".lora_A", G * r * kin))
+                    segs += [(p + pj + ".lora_B", nout * r) for pj in projs]
+                    if self.adalora:
+                        segs.append((p + site + ".lora_E", G * r))
         if self.lora:
             for i in reversed(range(self.n_lora)):
                 p = f"model.encoder.layers.{i}."
@@ -242,6 +267,15 @@ class MegWhisperEngine:
                 for nm, (no, ki) in (("self_attn.out_proj", (d, d)), ("fc1", (f, d)), ("fc2", (d, f))):
                     init_pair(self.pview(p + nm + ".lora_A").view(r, ki), self.pview(p + nm + ".lora_B").view(no, r),
                               self.pview(p + nm + ".lora_E") if self.adalora else None, p + nm)
+            if self.dec_lora:
+                for i in range(dims.dec_layers):
+                    p = f"model.decoder.layers.{i}."
+                    for site, _, projs, kin, nout, _ in _dec_sites(d, f):
+                        G = len(projs)
+                        A = self.pview(p + site + ".lora_A").view(G, r, kin)
+                        E = self.pview(p + site + ".lora_E").view(G, r) if self.adalora else None
+                        for j, pj in enumerate(projs):
+                            init_pair(A[j], self.pview(p + pj + ".lora_B").view(nout, r), E[j] if self.adalora else None, p + pj)
         self._build_operand_copies()
 
     def pview(self, name):
@@ -298,6 +332,27 @@ class MegWhisperEngine:
                     jobs.append((pp(p + nm + ".lora_B"), o[key + "_sB"].data_ptr(), no, r, r, r, sc, 0, ecol))
                     jobs.append((pp(p + nm + ".lora_B"), o[key + "_sBT"].data_ptr(), no, r, r, no, sc, 1, ecol))
                 self.lora_ops.append(o)
+        self.dec_ads = []
+        if self.dec_lora:
+            sc, qs = self.lora.scale, 64 ** -0.5
+            for i in range(dims.dec_layers):
+                p = f"model.decoder.layers.{i}."
+                ads = {}
+                for site, lin, projs, kin, nout, enc_rows in _dec_sites(d, f):
+                    G = len(projs)
+                    ad = {"site": p + site, "projs": [p + pj for pj in projs], "G": G, "kin": kin, "nout": nout,
+                          "enc_rows": enc_rows, "A": z(G * r, kin), "AT": z(kin, G * r), "sB": z(G * nout, r),
+                          "sBT": [z(r, nout) for _ in range(G)],
+                          "alpha": [sc * qs if pj.endswith("q_proj") else sc for pj in projs]}
+                    jobs.append((pp(p + site + ".lora_A"), ad["A"].data_ptr(), G * r, kin, kin, kin, 1.0, 0))
+                    jobs.append((pp(p + site + ".lora_A"), ad["AT"].data_ptr(), G * r, kin, kin, G * r, 1.0, 1))
+                    for j, pj in enumerate(projs):
+                        src = pp(p + pj + ".lora_B")
+                        ecol = pp(p + site + ".lora_E") + 4 * j * r if self.adalora else 0
+                        jobs.append((src, ad["sB"].data_ptr() + 2 * j * nout * r, nout, r, r, r, ad["alpha"][j], 0, ecol))
+                        jobs.append((src, ad["sBT"][j].data_ptr(), nout, r, r, nout, ad["alpha"][j], 1, ecol))
+                    ads[lin] = ad
+                self.dec_ads.append(ads)
         self._job_table, self._njobs = ops.make_cast_jobs(jobs, self.dev)
         self._orth_table = None
         if self.adalora:
@@ -312,6 +367,12 @@ class MegWhisperEngine:
                 for nm, no, ki in (("self_attn.out_proj", d, d), ("fc1", f, d), ("fc2", d, f)):
                     oj.append((pp(p + nm + ".lora_A"), gp(p + nm + ".lora_A"), rr, ki, ki, 0))
                     oj.append((pp(p + nm + ".lora_B"), gp(p + nm + ".lora_B"), rr, no, r, 1))
+            for ads in self.dec_ads:
+                for ad in ads.values():
+                    G, kin, nout = ad["G"], ad["kin"], ad["nout"]
+                    for j, pj in enumerate(ad["projs"]):
+                        oj.append((pp(ad["site"] + ".lora_A") + 4 * j * r * kin, gp(ad["site"] + ".lora_A") + 4 * j * r * kin, rr, kin, kin, 0))
+                        oj.append((pp(pj + ".lora_B"), gp(pj + ".lora_B"), rr, nout, r, 1))
             self._orth_table, self._n_orth = ops.make_orth_jobs(oj, self.dev)
             self.reg_dev = torch.zeros(1, device=self.dev)
             self._gbf = torch.zeros(max(d, f) * r, device=self.dev, dtype=F32)
@@ -386,6 +447,10 @@ class MegWhisperEngine:
             b["lse_c"] = [f32(B, H, L) for _ in range(ndl)]
             b["pre_fd"] = [h16(ML, f) for _ in range(ndl)]
             b["gfd"] = [h16(ML, f) for _ in range(ndl)]
+            if self.dec_lora:
+                for lin, G, rows in (("qkv", 3, ML), ("out", 1, ML), ("cq", 1, ML), ("ckv", 2, M), ("cout", 1, ML),
+                                     ("fc1", 1, ML), ("fc2", 1, ML)):
+                    b["ud_" + lin] = [h16(rows, G * r) for _ in range(ndl)]
             b["xd"] = h16(ML, d)
             b["st_d"] = (f32(ML), f32(ML))
             b["logits"] = h16(ML, dims.vocab_pad)
@@ -404,6 +469,9 @@ class MegWhisperEngine:
             if r:
                 b["du3"] = h16(M, 3 * r)
                 b["du"] = h16(M, r)
+            if self.dec_lora:
+                b["ddu"] = h16(ML, 3 * r)
+                b["ddu_kv"] = h16(M, 2 * r)
             b["ddh32"] = f32(ML, d)
             b["ddh16"] = h16(ML, d)
             b["ddx16"] = h16(ML, d)
@@ -439,6 +507,27 @@ class MegWhisperEngine:
                  R32=R32, H32=H32, h32m=rowmap(lin.K) if H32 is not None else None,
                  flags=NS_GEMM_MUL_P16 if P16 is not None else 0,
                  drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
+
+    def _ad_fwd(self, ad, x16, rows, lin: _Lin, u16, seed, **kw):
+        """adapted linear, forward: u = drop(x) A^T / keep (all groups stacked), y = x W^T + b + u_g sB_g^T"""
+        r, G, dp = self.r, ad["G"], self._drop_p()
+        ops.gemm(A=x16, am=rowmap(ad["kin"]), K=ad["kin"], B=ad["A"], ldb=ad["kin"], M=rows, N=G * r, C16=u16,
+                 c16m=rowmap(G * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
+        self._lin(x16, rows, lin, A2=u16, lda2=G * r, K2=r, B2=ad["sB"], ngroup=ad["nout"] if G > 1 else 0, **kw)
+
+    def _ad_bwd(self, ad, dy16, rows, lin: _Lin, x16, u16, du16, seed, out16, **kw):
+        """adapted linear, backward: du_g = dy_g sB_g / keep, dB_g = s dy_g^T u_g, dA = du^T drop(x),
+        dx = dy W + mask * (du A)"""
+        r, G, nout, kin = self.r, ad["G"], ad["nout"], ad["kin"]
+        ldy = G * nout
+        for g in range(G):
+            ops.gemm(A=(dy16, g * nout), am=rowmap(ldy), K=nout, B=ad["sBT"][g], ldb=nout, M=rows, N=r, C16=(du16, g * r),
+                     c16m=rowmap(G * r), alpha=self._drop_inv())
+            self._wgrad_b((dy16, g * nout), ldy, (u16, g * r), G * r, rows, nout, ad["projs"][g], ad["alpha"][g],
+                          ename=ad["site"] + ".lora_E", eoff=g * r)
+        self._with_seed(seed, lambda: self._wgrad(du16, G * r, x16, kin, rows, G * r, kin, ad["site"] + ".lora_A", drop=True))
+        self._with_seed(seed, lambda: self._dgrad(dy16, rows, lin, out16, A2=du16, lda2=G * r, K2=G * r, B2=ad["AT"],
+                                                   drop=True, **kw))
 
     def _drop_p(self):
         return self.lora.dropout if (self.lora and self.training_mode) else 0.0
@@ -564,22 +653,30 @@ class MegWhisperEngine:
             else:
                 h0, h1, h2, h3 = hd[0], hd[1], hd[0], hd[1]
                 # eval ping-pong: after the layer the stream must be back in hd[0]
+            ads = self.dec_ads[i] if self.dec_lora else None
+            sd0 = self._layer_seed(dims.enc_layers + i)
+
+            def lin(key, x16, rows, site_no, **kw):
+                if ads is None:
+                    self._lin(x16, rows, Lw[key], **kw)
+                else:
+                    self._ad_fwd(ads[key], x16, rows, Lw[key], b["ud_" + key][j], sd0 + site_no, **kw)
             ops.layernorm_fwd(h0, *Lw["ln1"], b["xs"][j], *b["st_s"][j], ML, d)
-            self._lin(b["xs"][j], ML, Lw["qkv"], C16=b["qkv_s"][j])
+            lin("qkv", b["xs"][j], ML, 0, C16=b["qkv_s"][j])
             q = b["qkv_s"][j]
             ops.attn_fwd(Q=q, K=(q, d), V=(q, 2 * d), O=b["ao_s"][j], B=B, H=H, Lq=L, Lk=L, ldq=3 * d, ldk=3 * d,
                          ldv=3 * d, ldo=d, causal=True, LSE=b["lse_s"][j])
-            self._lin(b["ao_s"][j], ML, Lw["out"], R32=h0, H32=h1)
+            lin("out", b["ao_s"][j], ML, 1, R32=h0, H32=h1)
             ops.layernorm_fwd(h1, *Lw["ln2"], b["xc"][j], *b["st_c"][j], ML, d)
-            self._lin(b["xc"][j], ML, Lw["cq"], C16=b["q_c"][j])
-            self._lin(enc16, M, Lw["ckv"], C16=b["kv_c"][j])
+            lin("cq", b["xc"][j], ML, 2, C16=b["q_c"][j])
+            lin("ckv", enc16, M, 3, C16=b["kv_c"][j])
             kv = b["kv_c"][j]
             ops.attn_fwd(Q=b["q_c"][j], K=kv, V=(kv, d), O=b["ao_c"][j], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
                          ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][j])
-            self._lin(b["ao_c"][j], ML, Lw["cout"], R32=h1, H32=h2)
+            lin("cout", b["ao_c"][j], ML, 4, R32=h1, H32=h2)
             ops.layernorm_fwd(h2, *Lw["ln3"], b["xm"][j], *b["st_m"][j], ML, d)
-            self._lin(b["xm"][j], ML, Lw["fc1"], C16=b["pre_fd"][j], G16=b["gfd"][j], gelu=True)
-            self._lin(b["gfd"][j], ML, Lw["fc2"], R32=h2, H32=h3)
+            lin("fc1", b["xm"][j], ML, 5, C16=b["pre_fd"][j], G16=b["gfd"][j], gelu=True)
+            lin("fc2", b["gfd"][j], ML, 6, R32=h2, H32=h3)
             if not train and h3 is not hd[0]:
                 hd[0].copy_(h3)
         hl = hd[3 * dims.dec_layers] if train else hd[0]
@@ -646,29 +743,38 @@ class MegWhisperEngine:
         for i in reversed(range(dims.dec_layers)):
             Lw = self.dec[i]
             h0, h1, h2 = hd[3 * i], hd[3 * i + 1], hd[3 * i + 2]
+            ads = self.dec_ads[i] if self.dec_lora else None
+            sd0 = self._layer_seed(dims.enc_layers + i)
+
+            def dgrad(key, dy16, rows, x16, site_no, out16, **kw):
+                if ads is None:
+                    self._dgrad(dy16, rows, Lw[key], out16, **kw)
+                else:
+                    self._ad_bwd(ads[key], dy16, rows, Lw[key], x16, b["ud_" + key][i],
+                                 b["ddu_kv"] if key == "ckv" else b["ddu"], sd0 + site_no, out16, **kw)
             # MLP
-            self._dgrad(b["ddh16"], ML, Lw["fc2"], b["ddpre_f"], P16=b["pre_fd"][i])
-            self._dgrad(b["ddpre_f"], ML, Lw["fc1"], b["ddx16"])
+            dgrad("fc2", b["ddh16"], ML, b["gfd"][i], 6, b["ddpre_f"], P16=b["pre_fd"][i])
+            dgrad("fc1", b["ddpre_f"], ML, b["xm"][i], 5, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h2, *b["st_m"][i], Lw["ln3"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
             # cross attention
-            self._dgrad(b["ddh16"], ML, Lw["cout"], b["ddao"])
+            dgrad("cout", b["ddh16"], ML, b["ao_c"][i], 4, b["ddao"])
             kv = b["kv_c"][i]
             ops.attn_bwd(Q=b["q_c"][i], K=kv, V=(kv, d), O=b["ao_c"][i], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
                          ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][i], dO=b["ddao"], dQ=b["ddq_c"], dK=b["dkv_c"],
                          dV=(b["dkv_c"], d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
-            self._dgrad(b["ddq_c"], ML, Lw["cq"], b["ddx16"])
+            dgrad("cq", b["ddq_c"], ML, b["xc"][i], 2, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h1, *b["st_c"][i], Lw["ln2"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
             # encoder-state gradient accumulates in fp32 across the decoder layers
-            self._dgrad(b["dkv_c"], M, Lw["ckv"], None, R32=None if first_enc else b["denc32"], H32=b["denc32"])
+            dgrad("ckv", b["dkv_c"], M, b["enc16"], 3, None, R32=None if first_enc else b["denc32"], H32=b["denc32"])
             first_enc = False
             # causal self attention
-            self._dgrad(b["ddh16"], ML, Lw["out"], b["ddao"])
+            dgrad("out", b["ddh16"], ML, b["ao_s"][i], 1, b["ddao"])
             q = b["qkv_s"][i]
             dq = b["ddqkv"]
             ops.attn_bwd(Q=q, K=(q, d), V=(q, 2 * d), O=b["ao_s"][i], B=B, H=H, Lq=L, Lk=L, ldq=3 * d, ldk=3 * d,
                          ldv=3 * d, ldo=d, causal=True, LSE=b["lse_s"][i], dO=b["ddao"], dQ=dq, dK=(dq, d),
                          dV=(dq, 2 * d), Delta=b["ddelta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
-            self._dgrad(dq, ML, Lw["qkv"], b["ddx16"])
+            dgrad("qkv", dq, ML, b["xs"][i], 0, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h0, *b["st_s"][i], Lw["ln1"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
         # ---- encoder
         h = b["h"]
@@ -736,6 +842,8 @@ class MegWhisperEngine:
                 # adapter gradients of layers [i, hi_l] are final: two chunks (upper half, lower half of the adapted layers)
                 hi_l = nl - 1 if (i == nl // 2 and i != 0) or nl // 2 == 0 else nl // 2 - 1
                 lo_off = self.seg_off[f"model.encoder.layers.{hi_l}.self_attn.qkv.lora_A"][0]
+                if hi_l == nl - 1:
+                    lo_off = 0      # --ft_full: the decoder adapters (front of the buffer) were final before the encoder started
                 end = self.lora_end if i == 0 else self.seg_off[f"model.encoder.layers.{i - 1}.self_attn.qkv.lora_A"][0]
                 on_ready(lo_off, end)
         r = rank

@@ -38,6 +38,9 @@ class Generator:
                  begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
                  pad_id: int | None = None, check_every: int = 4) -> torch.Tensor:
         eng = self.eng
+        if getattr(eng, "dec_lora", False):
+            raise RuntimeError("decode from merged weights (merge_and_unload / merge_lora.py): the generation loop does not "
+                               "carry decoder adapters")
         dims, dev = eng.dims, eng.dev
         d, H, S, V, Vp = dims.d, dims.heads, dims.src_pos, dims.vocab, dims.vocab_pad
         eos = dims.eos_id if eos_id is None else eos_id

@@ -67,6 +67,20 @@ def _expected_targets(model):
     return names
 
 
+def _decoder_targets(model):
+    """the ten adapted Linear modules of every decoder layer with --ft_full (finetune.py:191-192, prefixes = ['model'])"""
+    names = []
+    for i in range(len(model.model.decoder.layers)):
+        p = f"model.decoder.layers.{i}."
+        for suf in LORA_SUFFIXES:
+            names += [p + suf] if suf.startswith("fc") else [p + f"self_attn.{suf}", p + f"encoder_attn.{suf}"]
+    return names
+
+
+def targets_cover_decoder(model, target_modules) -> bool:
+    return set(target_modules) == set(_expected_targets(model)) | set(_decoder_targets(model))
+
+
 class _Base(nn.Module):
     def __init__(self, model):
         super().__init__()
@@ -87,10 +101,12 @@ class PeftModel(nn.Module):
         full = _expected_targets(model)
         n = len(config.target_modules)
         # all six Linear modules of the first N encoder layers (N = all: finetune.py:194, N < all: --fine_tune_layers :189-190)
-        if n == 0 or n % len(LORA_SUFFIXES) or set(config.target_modules) != set(full[:n]):
+        # or every encoder AND decoder projection (--ft_full, :191-192)
+        if not targets_cover_decoder(model, config.target_modules) and \
+                (n == 0 or n % len(LORA_SUFFIXES) or set(config.target_modules) != set(full[:n])):
             raise NotImplementedError("the HIP engine carries adapters on q/k/v/out/fc1/fc2 of the first N encoder layers "
-                                      f"(N = 1..{len(full) // len(LORA_SUFFIXES)}); got {n} target modules that are not such a set "
-                                      "(--ft_full / decoder adapters are outside the hot path)")
+                                      f"(N = 1..{len(full) // len(LORA_SUFFIXES)}) or of the whole model (--ft_full); got {n} "
+                                      "target modules that are neither")
         ada = isinstance(config, AdaLoraConfig)
         if not ada and config.r % 16:
             raise NotImplementedError("LoRA rank must be a multiple of 16 (MFMA K granularity)")

@@ -122,23 +122,32 @@ def make_state_dict(dims: WhisperDims, seed: int = 42, frontend: str = "base") -
 LORA_SUFFIXES = ("k_proj", "q_proj", "v_proj", "out_proj", "fc1", "fc2")
 
 
-def make_lora_state(dims: WhisperDims, r: int, seed: int = 7, b_std: float = 0.02, adalora: bool = False) -> dict[str, np.ndarray]:
-    """LoRA A/B for every encoder q/k/v/out/fc1/fc2 (finetune.py:189-198).  PEFT initialises B to zero; tests use
-    a non-zero B (b_std) so the side path and its gradients are exercised."""
+def make_lora_state(dims: WhisperDims, r: int, seed: int = 7, b_std: float = 0.02, adalora: bool = False,
+                    decoder: bool = False) -> dict[str, np.ndarray]:
+    """LoRA A/B for every encoder q/k/v/out/fc1/fc2 (finetune.py:189-198) and, with decoder=True, for every decoder
+    projection as well (--ft_full, finetune.py:191-192).  PEFT initialises B to zero; tests use a non-zero B (b_std)
+    so the side path and its gradients are exercised."""
     d, f = dims.d, dims.ffn
     out = {}
+    names = []
     for i in range(dims.enc_layers):
-        for suf in LORA_SUFFIXES:
-            if suf in ("fc1", "fc2"):
-                name = f"model.encoder.layers.{i}.{suf}"
-            else:
-                name = f"model.encoder.layers.{i}.self_attn.{suf}"
-            in_f = f if suf == "fc2" else d
-            out_f = f if suf == "fc1" else d
-            out[name + ".lora_A.weight"] = _gen(name + ".lora_A", (r, in_f), in_f ** -0.5, seed)
-            out[name + ".lora_B.weight"] = _gen(name + ".lora_B", (out_f, r), b_std, seed)
-            if adalora:   # peft initialises E to zero; tests use a non-zero E so that every gradient path is live
-                out[name + ".lora_E.weight"] = _gen(name + ".lora_E", (r, 1), 0.5, seed)
+        p = f"model.encoder.layers.{i}."
+        names += [(p + (suf if suf in ("fc1", "fc2") else f"self_attn.{suf}"), suf) for suf in LORA_SUFFIXES]
+    if decoder:
+        for i in range(dims.dec_layers):
+            p = f"model.decoder.layers.{i}."
+            for suf in LORA_SUFFIXES:
+                if suf in ("fc1", "fc2"):
+                    names.append((p + suf, suf))
+                else:
+                    names += [(p + f"self_attn.{suf}", suf), (p + f"encoder_attn.{suf}", suf)]
+    for name, suf in names:
+        in_f = f if suf == "fc2" else d
+        out_f = f if suf == "fc1" else d
+        out[name + ".lora_A.weight"] = _gen(name + ".lora_A", (r, in_f), in_f ** -0.5, seed)
+        out[name + ".lora_B.weight"] = _gen(name + ".lora_B", (out_f, r), b_std, seed)
+        if adalora:   # peft initialises E to zero; tests use a non-zero E so that every gradient path is live
+            out[name + ".lora_E.weight"] = _gen(name + ".lora_E", (r, 1), 0.5, seed)
     return out
 
 

@@ -119,7 +119,7 @@ def causal_mask(Lq, Lk, dtype=torch.float32):
     return m
 
 
-def decoder(sd, dec_ids, enc, dims, pos0=0):
+def decoder(sd, dec_ids, enc, dims, pos0=0, lora=None, scale=0.0):
     """utils/load_model.py:645-749 + HF:416-506: embed_tokens + positions[pos0:pos0+L], then per layer
     causal self-attn, cross-attn over encoder states, GELU MLP (all pre-LN), final LayerNorm."""
     dd = "model.decoder."
@@ -129,10 +129,12 @@ def decoder(sd, dec_ids, enc, dims, pos0=0):
     for i in range(dims.dec_layers):
         p = f"{dd}layers.{i}."
         x = _ln(sd, p + "self_attn_layer_norm", h)
-        h = h + attention(sd, None, p + "self_attn", x, x, dims.heads, mask, 0.0)
-        h = h + attention(sd, None, p + "encoder_attn", _ln(sd, p + "encoder_attn_layer_norm", h), enc, dims.heads, None, 0.0)
+        # adapters on the decoder projections only with finetune.py --ft_full (:191-192); _lora_lin is the plain linear
+        # for modules without lora_A / lora_B entries
+        h = h + attention(sd, lora, p + "self_attn", x, x, dims.heads, mask, scale)
+        h = h + attention(sd, lora, p + "encoder_attn", _ln(sd, p + "encoder_attn_layer_norm", h), enc, dims.heads, None, scale)
         m = _ln(sd, p + "final_layer_norm", h)
-        h = h + F.linear(F.gelu(F.linear(m, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+        h = h + _lora_lin(F.gelu(_lora_lin(m, sd, lora, p + "fc1", scale)), sd, lora, p + "fc2", scale)
     return _ln(sd, dd + "layer_norm", h)
 
 
@@ -149,7 +151,7 @@ def forward(sd, x, dims, labels=None, dec_ids=None, lora=None, scale=0.0):
     if dec_ids is None:
         dec_ids = shift_tokens_right(labels, dims.pad_id, dims.start_id)
     enc = encoder(sd, x, dims, lora, scale)
-    hid = decoder(sd, dec_ids, enc, dims)
+    hid = decoder(sd, dec_ids, enc, dims, lora=lora, scale=scale)
     logits = F.linear(hid, sd["model.decoder.embed_tokens.weight"])
     loss = None
     if labels is not None:

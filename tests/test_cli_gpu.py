@@ -193,3 +193,60 @@ def test_adalora_module_api_grads_and_merge(dev):
     assert out.loss.item() > ev_loss   # the training loss carries the orthogonality penalty, evaluation does not
     assert abs(ev_loss - b.loss.item()) < 5e-3
     torch.testing.assert_close(a_logits, b.logits.float(), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("adalora", [False, True])
+def test_finetune_full_model_adapters_then_decode(dev, tmp_path, adalora):
+    """--ft_full=True (finetune.py:64,191-192): adapters on every encoder and decoder projection; the checkpoint carries
+    the decoder tensors under PEFT's names, evaluation.py merges them and decodes, merge_lora.py exports the same model."""
+    import evaluation
+    import finetune
+    import merge_lora
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 12, ch_file=24, name="toyset", seed=3, min_len=120, max_len=520)
+    out = str(tmp_path / "out")
+    common = ["--modal=eeg", "--eeg_ch=20", "--sampling_rate=200", "--timestamps=False", "--max_audio_len=2.0",
+              "--language=Dutch", "--num_workers=0"]
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}",
+                   "--orig_sample_rate=200", f"--use_adalora={adalora}", "--fp16=True", "--num_train_epochs=2",
+                   "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
+                   "--eval_steps=3", "--save_steps=3", "--warmup_steps=0", "--learning_rate=1e-3",
+                   "--augment_config_path=None", "--ft_full=True"] + common)
+    logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_tiny", "train_log.jsonl"))]
+    assert len(logs) == 6 and logs[-1]["loss"] < logs[0]["loss"], logs
+    ck = os.path.join(out, "synthetic_tiny", "checkpoint-final")
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(ck, "adapter_model.safetensors"))
+    suffix = "" if adalora else ".weight"
+    n_dec = 0
+    for i in range(2):
+        for site in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
+                     "encoder_attn.k_proj", "encoder_attn.v_proj", "encoder_attn.out_proj", "fc1", "fc2"):
+            k = f"base_model.model.model.decoder.layers.{i}.{site}"
+            assert k + ".lora_A" + suffix in sd and k + ".lora_B" + suffix in sd, k
+            moved = sd[k + (".lora_E" if adalora else ".lora_B" + suffix)]
+            assert moved.abs().sum() > 0, k          # B (LoRA) / E (AdaLoRA) start at zero: the decoder adapters were trained
+            n_dec += 1
+    assert n_dec == 20
+    cfg = json.load(open(os.path.join(ck, "adapter_config.json")))
+    assert len(cfg["target_modules"]) == 2 * 6 + 2 * 10
+    evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                     "--max_new_tokens=8"] + common)
+    hyp_adapter = open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).read()
+    assert len(hyp_adapter.splitlines()) == 12
+    full = merge_lora.main([f"--lora_model={ck}", "--model_path=synthetic:tiny", "--eeg_ch=20"])
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        evaluation.main([f"--test_data={jl}", f"--model_path={full}", "--batch_size=4", "--max_new_tokens=8"] + common)
+        assert open("formal_test_resultsno_post_processing.jsonl").read() == hyp_adapter
+    finally:
+        os.chdir(cwd)
+    # resuming from the checkpoint restores the decoder adapters into the engine
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out}2",
+                   "--orig_sample_rate=200", f"--use_adalora={adalora}", "--fp16=True", "--num_train_epochs=1",
+                   "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
+                   "--eval_steps=100", "--save_steps=100", "--warmup_steps=0", "--learning_rate=1e-4",
+                   "--augment_config_path=None", "--ft_full=True", f"--resume_from_checkpoint={ck}", "--max_steps=2"] + common)
+    logs2 = [json.loads(l) for l in open(os.path.join(out + "2", "synthetic_tiny", "train_log.jsonl"))]
+    assert logs2[0]["loss"] < logs[0]["loss"], (logs2, logs)     # it starts from the trained adapters, not from scratch

@@ -333,3 +333,69 @@ def test_rccl_reducer_on_the_side_stream_single_rank(dev):
         assert sorted(calls[:3])[0][0] == 0 and max(h for _, h in calls[:3]) == eng_b.n_train
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("adalora", [False, True])
+def test_full_model_adapters_vs_oracle(dev, adalora):
+    """--ft_full (finetune.py:191-192): adapters on every decoder projection too (self q/k/v/out, cross q/k/v/out,
+    fc1, fc2).  Loss, encoder AND decoder adapter gradients and the conv stem against the oracle; then it trains with
+    dropout on."""
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg, _dec_sites
+    from oracle import whisper_meg_oracle as O
+    dims, r = TINY, (12 if adalora else 16)
+    sd = make_state_dict(dims, 42)
+    # moderate adapter size: with ten adapted sites per decoder layer a B of std 0.3 dominates the frozen weights and the
+    # fp16 gradient error compounds to 10-20 % by the bottom layer (0.1-0.5 % at this size)
+    lora_sd = make_lora_state(dims, r, adalora=adalora, b_std=0.1 if adalora else 0.05, decoder=True)
+    spec = LoraSpec(r=r, alpha=32.0, dropout=0.0, adalora=adalora, orth_reg_weight=0.5 if adalora else 0.0, decoder=True)
+    eng = MegWhisperEngine(dims, sd, lora=spec, lora_sd=lora_sd, train_cfg=TrainCfg(), device=dev)
+    x, labels = synth_batch(dims, 3, 11)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, spec.scale, orth_reg_weight=spec.orth_reg_weight)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss.item(), o_loss.item())
+    s = eng.loss_scale_dev.item()
+    d, f, rp = dims.d, dims.ffn, eng.r
+    bad, n = {}, 0
+    for i in range(dims.dec_layers):
+        p = f"model.decoder.layers.{i}."
+        for site, _, projs, kin, nout, _ in _dec_sites(d, f):
+            G = len(projs)
+            A = eng.gview(p + site + ".lora_A").view(G, rp, kin).cpu() / s
+            E = eng.gview(p + site + ".lora_E").view(G, rp).cpu() / s if adalora else None
+            for j, pj in enumerate(projs):
+                got = {"lora_A": A[j, :r], "lora_B": eng.gview(p + pj + ".lora_B").view(nout, rp)[:, :r].cpu() / s}
+                if adalora:
+                    got["lora_E"] = E[j, :r].reshape(r, 1)
+                for k, v in got.items():
+                    e = rel(v, og[p + pj + f".{k}.weight"])
+                    n += 1
+                    if not e < 3e-2:
+                        bad[p + pj + "." + k] = e
+                assert rp == r or A[j, r:].abs().max() == 0, "padded ranks must stay dead"
+    assert n == dims.dec_layers * 10 * (3 if adalora else 2)
+    # the encoder side still matches with the decoder adapters in the graph (its input gradient now carries the cross
+    # K/V adapters' contribution)
+    for i in range(dims.enc_layers):
+        p = f"model.encoder.layers.{i}."
+        for nm, no, ki in (("self_attn.out_proj", d, d), ("fc1", f, d), ("fc2", d, f)):
+            for k, v in (("lora_A", eng.gview(p + nm + ".lora_A").view(rp, ki)[:r].cpu() / s),
+                         ("lora_B", eng.gview(p + nm + ".lora_B").view(no, rp)[:, :r].cpu() / s)):
+                e = rel(v, og[p + nm + f".{k}.weight"])
+                if not e < 3e-2:
+                    bad[p + nm + "." + k] = e
+    assert not bad, bad
+    assert rel(eng.conv_weight_grad("conv2").float().cpu() / s, og["model.encoder.conv2.weight"]) < 3e-2
+    # trains with dropout on; the eval forward through the adapters agrees with the oracle's logits
+    torch.manual_seed(0)
+    eng2 = MegWhisperEngine(dims, sd, lora=LoraSpec(r=r, alpha=32.0, dropout=0.1, adalora=adalora, decoder=True), lora_sd=lora_sd,
+                            train_cfg=TrainCfg(lr=1e-3, warmup_steps=0, total_steps=0), device=dev)
+    _, lg = eng2.forward(xd, ld, train=False)
+    _, o_logits, _ = O.forward({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, torch.from_numpy(x), dims,
+                               labels=torch.from_numpy(labels), lora={k: torch.from_numpy(v) for k, v in lora_sd.items()},
+                               scale=spec.scale)
+    assert rel(lg.float().cpu(), o_logits) < 1e-2
+    ls = [eng2.train_step(xd, ld).item() for _ in range(5)]
+    assert ls[-1] < ls[0] and eng2.found_inf_dev.item() == 0, ls

@@ -44,6 +44,23 @@ def test_oracle_lora_equals_reference_on_merged_weights():
     np.testing.assert_allclose(logits.numpy(), g["logits"], atol=5e-4, rtol=1e-4)
 
 
+def test_oracle_full_model_lora_equals_reference_on_merged_weights():
+    """--ft_full: adapters on the decoder projections too, pinned the same way (tools/make_goldens.py lora_full)"""
+    g = np.load(os.path.join(G, "lora_merged_tiny_full.npz"))
+    r, alpha = int(g["r"]), float(g["alpha"])
+    sd = make_state_dict(TINY, 42)
+    lora = make_lora_state(TINY, r, decoder=True)
+    x, labels = synth_batch(TINY, int(g["B"]), 1234)
+    with torch.no_grad():
+        loss, logits, _ = O.forward(O.to_torch(sd), torch.from_numpy(x), TINY, labels=torch.from_numpy(labels),
+                                    lora=O.to_torch(lora), scale=alpha / r)
+        loss_enc_only, _, _ = O.forward(O.to_torch(sd), torch.from_numpy(x), TINY, labels=torch.from_numpy(labels),
+                                        lora=O.to_torch(make_lora_state(TINY, r)), scale=alpha / r)
+    assert abs(loss.item() - float(g["loss"])) < 5e-5
+    assert abs(loss_enc_only.item() - float(g["loss"])) > 1e-3       # the decoder adapters matter in this fixture
+    np.testing.assert_allclose(logits.numpy()[:, :, ::7], g["logits"], atol=5e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("tag,ch,B", [("base208", 208, 2)])
 def test_oracle_matches_reference_base_shape(tag, ch, B):
     g = np.load(os.path.join(G, f"train_{tag}.npz"))

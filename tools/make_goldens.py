@@ -95,19 +95,21 @@ def train_golden(dims, tag, B, seed_w=42, seed_d=1234, full=True):
     return sd_np, x, labels
 
 
-def lora_golden(dims, tag, B, r=32, alpha=64.0):
-    """LoRA is pinned through merged-weight equivalence: the reference object run on W + (alpha/r) B A."""
+def lora_golden(dims, tag, B, r=32, alpha=64.0, decoder=False):
+    """LoRA is pinned through merged-weight equivalence: the reference object run on W + (alpha/r) B A.
+    decoder=True: adapters on every decoder projection as well (finetune.py --ft_full); logits kept as a slice."""
     sys.path.insert(0, os.path.join(ROOT))
     from oracle.whisper_meg_oracle import lora_merge
     sd_np = make_state_dict(dims, 42)
-    lora_np = make_lora_state(dims, r)
+    lora_np = make_lora_state(dims, r, decoder=decoder)
     merged = lora_merge(sd_np, lora_np, alpha / r)
     model = build_hf(dims, merged)
     x, labels = synth_batch(dims, B, 1234)
     with torch.no_grad():
         out = model(input_features=torch.from_numpy(x), labels=torch.from_numpy(labels))
+    lg = out.logits.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, f"lora_merged_{tag}.npz"), loss=np.float32(out.loss.item()),
-                        logits=out.logits.numpy().astype(np.float32), r=r, alpha=alpha, B=B)
+                        logits=lg[:, :, ::7] if decoder else lg, r=r, alpha=alpha, B=B)
     print(f"lora_merged_{tag}: loss {out.loss.item():.6f}")
 
 
@@ -160,6 +162,8 @@ if __name__ == "__main__":
         train_golden(WhisperDims(ch=273), "base273", B=1, full=False)
     if "lora" in what:
         lora_golden(TINY, "tiny", B=2)
+    if "lora_full" in what:
+        lora_golden(TINY, "tiny_full", B=2, decoder=True)
     if "decode" in what:
         decode_golden(TINY, "tiny", B=3, new_tokens=24)
     if "decode_base" in what:
