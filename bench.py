@@ -17,6 +17,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: RCCL across processes needs this (already exported on the GPU box)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # algorithmic work per training sample, fwd+bwd: whisper-base, L=32, LoRA r=32
 GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}

@@ -10,6 +10,8 @@ warmup/decay; eval = loss only; a checkpoint is written only when the eval loss 
 (utils/callback.py:11-32) plus `checkpoint-final` at the end.
 """
 import argparse
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL across processes on this pool
 import functools
 import json
 import math
