@@ -56,14 +56,16 @@ def build_parser():
     add_arg("num_beams", type=int, default=5, help="beam width (reference: 5)")
     add_arg("max_new_tokens", type=int, default=None, help="cap on generated tokens")
     add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack)")
+    add_arg("sequence_bias_type", type=str, default="phrase_word", choices=["word", "phrase", "phrase_word"],
+            help="what --add_sequence_bias extracts from the training sentences (reference: phrase_word, needs yake)")
     return parser
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print_arguments(args)
-    if args.random_choice or args.add_sequence_bias:
-        raise NotImplementedError("--random_choice / --add_sequence_bias are outside the hot path")
+    if args.random_choice:
+        raise NotImplementedError("--random_choice (labels shuffled as predictions, no model involved) is outside the hot path")
     assert args.model_path.startswith("synthetic:") or os.path.exists(args.model_path), f"model {args.model_path} not found"
     from finetune import get_processor
     processor = get_processor(args.model_path, args.language, args.task, args.timestamps, args.local_files_only)
@@ -114,6 +116,13 @@ def main(argv=None):
             fut = stage(nxt)
             yield (cur_fut.result() if cur_fut is not None else cur["input_features"].to(model.device)), cur["labels"]
 
+    sequence_bias = None
+    if args.add_sequence_bias:      # reference :339-343: bias -1.0 on the words / key phrases of the training list
+        from utils.generation_helper import GetSequenceBias
+        tok = processor.tokenizer if args.model_path.startswith("synthetic:") else None
+        sequence_bias = GetSequenceBias(tokenizer_name=args.model_path, jsonl_path=args.test_data.replace("test.jsonl", "train.jsonl"),
+                                        bias=-1.0, extract_type=args.sequence_bias_type, tokenizer=tok).get_bias_for_my_sentences()
+        print(f"sequence bias: {len(sequence_bias)} token sequences")
     preds, refs = [], []
     n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
     with open(os.path.join(out_dir, base + ".txt"), "w") as f, torch.no_grad():
@@ -126,6 +135,8 @@ def main(argv=None):
                     kw["decoder_input_ids"] = labels[:, :4].to(model.device)
                 if args.max_new_tokens is not None:
                     kw["max_new_tokens"] = args.max_new_tokens
+                if sequence_bias is not None:
+                    kw["sequence_bias"] = sequence_bias
                 gen = model.generate(x, do_sample=False, num_beams=args.num_beams, repetition_penalty=5.0,
                                      no_repeat_ngram_size=2, **kw).cpu().numpy()
                 n_new += int(gen.shape[0] * (gen.shape[1] - (4 if kw.get("decoder_input_ids") is not None else 1)))

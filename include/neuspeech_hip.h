@@ -299,6 +299,13 @@ typedef struct {
   int32_t rows, V, ldv, ids_ld, cur_len, begin_index;
   int32_t n_suppress, n_begin_suppress, no_repeat_ngram, log_softmax;
   float repetition_penalty;
+  /* sequence bias (HF SequenceBiasLogitsProcessor, generation/logits_process.py; FIRST in HF's processor order, i.e.
+   * added right after the log-softmax and before the repetition penalty): bias1 = dense per-token bias of the
+   * length-1 sequences (V floats) or NULL; the n_seq longer sequences are seq_tok[seq_off[s] .. seq_off[s+1]) and add
+   * seq_bias[s] to their LAST token in every row whose history ends with the tokens before it.  ns_logits_process only
+   * (ns_logits_select refuses a descriptor that carries a bias). */
+  const float* bias1; const int32_t* seq_tok; const int32_t* seq_off; const float* seq_bias;
+  int32_t n_seq, reserved;
 } ns_logits_proc_desc;
 int ns_logits_process(const ns_logits_proc_desc* d, void* stream);
 

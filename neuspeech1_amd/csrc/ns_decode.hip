@@ -311,15 +311,47 @@ __global__ __launch_bounds__(256) void logits_process_kernel(const ns_logits_pro
     se = blk_reduce(se, false, sh);
     lse = mx + __logf(se);
   }
-  for (int c = tid; c < p.V; c += 256) out[c] = (float)lg[c] - lse;
+  const bool biased = p.bias1 != nullptr || p.n_seq > 0;
+  if (p.bias1) {
+    for (int c = tid; c < p.V; c += 256) out[c] = ((float)lg[c] - lse) + p.bias1[c];
+  } else {
+    for (int c = tid; c < p.V; c += 256) out[c] = (float)lg[c] - lse;
+  }
   __syncthreads();
+  if (p.n_seq > 0) {
+    // sequences of length >= 2: the row's history must end with all tokens but the last (HF adds once per sequence, so
+    // sequences that share their last token accumulate)
+    for (int sq = tid; sq < p.n_seq; sq += 256) {
+      const int o0 = p.seq_off[sq], len = p.seq_off[sq + 1] - o0, pre = len - 1;
+      if (pre < 1 || len > cur) continue;      // HF ignores sequences longer than the context (len > cur)
+      bool match = true;
+      for (int e = 0; e < pre; ++e) match = match && (ids[cur - pre + e] == (int64_t)p.seq_tok[o0 + e]);
+      const int last = p.seq_tok[o0 + pre];
+      if (match && last >= 0 && last < p.V) atomicAdd(&out[last], p.seq_bias[sq]);
+    }
+    __syncthreads();
+  }
   if (p.repetition_penalty != 1.f) {
-    // every occurrence recomputes from the ORIGINAL value, so duplicates write the same number
-    for (int t = tid; t < cur; t += 256) {
-      const int64_t tok = ids[t];
-      if (tok >= 0 && tok < p.V) {
-        const float b = (float)lg[tok] - lse;
-        out[tok] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+    if (!biased) {
+      // every occurrence recomputes from the ORIGINAL value, so duplicates write the same number
+      for (int t = tid; t < cur; t += 256) {
+        const int64_t tok = ids[t];
+        if (tok >= 0 && tok < p.V) {
+          const float b = (float)lg[tok] - lse;
+          out[tok] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+        }
+      }
+    } else {
+      // the penalised value is the BIASED score held in `out`: only the first occurrence of a token rewrites it
+      for (int t = tid; t < cur; t += 256) {
+        const int64_t tok = ids[t];
+        if (tok < 0 || tok >= p.V) continue;
+        bool first = true;
+        for (int e = 0; e < t; ++e) first = first && (ids[e] != tok);
+        if (first) {
+          const float b = out[tok];
+          out[tok] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+        }
       }
     }
     __syncthreads();
@@ -773,6 +805,7 @@ extern "C" int ns_logits_process(const ns_logits_proc_desc* d, void* stream) {
   NS_CHECK_ARG(d && d->logits16 && d->scores32 && d->ids, "ns_logits_process: null pointer");
   NS_CHECK_ARG(d->rows > 0 && d->V > 0 && d->ldv >= d->V && d->no_repeat_ngram >= 0, "ns_logits_process: bad shape");
   NS_CHECK_ARG(d->repetition_penalty > 0.f, "ns_logits_process: repetition_penalty must be > 0");
+  NS_CHECK_ARG(d->n_seq >= 0 && (d->n_seq == 0 || (d->seq_tok && d->seq_off && d->seq_bias)), "ns_logits_process: sequence-bias tables missing");
   hipLaunchKernelGGL(logits_process_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)stream, *d);
   NS_CHECK_LAUNCH("ns_logits_process");
   return NS_OK;
@@ -804,6 +837,7 @@ extern "C" int ns_logits_select(const ns_logits_proc_desc* d, int k, int group_r
                "ns_logits_select: ldv=%d must be a multiple of 8 and <= %d (use ns_logits_process + ns_topk_groups beyond)",
                d->ldv, SEL_MAX_LDV);
   NS_CHECK_ARG(k >= 1 && k <= 16 && group_rows >= 1 && d->cur_len >= 0 && d->cur_len <= d->ids_ld, "ns_logits_select: bad shape");
+  NS_CHECK_ARG(!d->bias1 && d->n_seq == 0, "ns_logits_select: sequence bias needs ns_logits_process + ns_topk_groups");
   NS_CHECK_ARG(d->n_suppress == 0 || d->suppress, "ns_logits_select: suppress list missing");
   NS_CHECK_ARG(d->n_begin_suppress == 0 || d->begin_suppress, "ns_logits_select: begin_suppress list missing");
   hipLaunchKernelGGL(logits_select_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)stream, *d, k, group_rows, cand_vals, cand_idx);

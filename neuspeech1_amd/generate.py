@@ -14,12 +14,49 @@ Design notes (MI355X-first):
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops
 from .ops import rowmap
 
 F16, F32 = torch.float16, torch.float32
+
+
+def _sequence_bias_tables(sequence_bias, V, dev):
+    """{(token ids): bias} or [[[token ids], bias], ...] (both forms of HF's `sequence_bias`) -> device tables of
+    ns_logits_proc_desc: a dense vector for the length-1 sequences, flattened tokens + offsets + biases for the rest.
+    Validation as HF generation/logits_process.py (SequenceBiasLogitsProcessor._validate_arguments)."""
+    if sequence_bias is None:
+        return {}
+    if isinstance(sequence_bias, list):
+        if len(sequence_bias) == 0 or any(len(s_) != 2 or not isinstance(s_[0], (list, tuple)) or len(s_[0]) == 0 for s_ in sequence_bias):
+            raise ValueError(f"`sequence_bias` has to be a non-empty dictionary, or non-empty list of lists but is {sequence_bias}.")
+        sequence_bias = {tuple(s_[0]): s_[1] for s_ in sequence_bias}
+    if not isinstance(sequence_bias, dict) or len(sequence_bias) == 0:
+        raise ValueError(f"`sequence_bias` has to be a non-empty dictionary, or non-empty list of lists but is {sequence_bias}.")
+    for ids, bias in sequence_bias.items():
+        if not isinstance(ids, tuple) or len(ids) == 0 or any((not isinstance(t, (int, np.integer))) or t < 0 for t in ids):
+            raise ValueError(f"Each key in `sequence_bias` has to be a non-empty tuple of positive integers, but is {sequence_bias}.")
+        if not isinstance(bias, float):
+            raise ValueError(f"`sequence_bias` has to be a dict with floats as values, but is {sequence_bias}.")
+    bad = [t for ids in sequence_bias for t in ids if t >= V]
+    if bad:
+        raise ValueError(f"The model vocabulary size is {V}, but the following tokens were being biased: {bad}")
+    out = {}
+    ones = {ids[0]: b for ids, b in sequence_bias.items() if len(ids) == 1}
+    if ones:
+        b1 = torch.zeros(V, dtype=F32)
+        b1[list(ones.keys())] = torch.tensor(list(ones.values()), dtype=F32)
+        out["bias1"] = b1.to(dev)
+    longer = [(ids, b) for ids, b in sequence_bias.items() if len(ids) > 1]
+    if longer:
+        off = np.cumsum([0] + [len(ids) for ids, _ in longer]).astype(np.int32)
+        out["seq_tok"] = torch.from_numpy(np.concatenate([np.asarray(ids, dtype=np.int32) for ids, _ in longer])).to(dev)
+        out["seq_off"] = torch.from_numpy(off).to(dev)
+        out["seq_bias"] = torch.tensor([b for _, b in longer], dtype=F32).to(dev)
+        out["n_seq"] = len(longer)
+    return out
 
 
 class Generator:
@@ -36,7 +73,7 @@ class Generator:
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
                  repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0, suppress_tokens=(),
                  begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
-                 pad_id: int | None = None, check_every: int = 4) -> torch.Tensor:
+                 pad_id: int | None = None, check_every: int = 4, sequence_bias=None) -> torch.Tensor:
         eng = self.eng
         if getattr(eng, "dec_lora", False):
             raise RuntimeError("decode from merged weights (merge_and_unload / merge_lora.py): the generation loop does not "
@@ -85,7 +122,9 @@ class Generator:
         gf = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
         st = (torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
         logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
-        fused_select = Vp <= ops.SELECT_MAX_LDV      # processors + per-row top-k in one pass, no fp32 score matrix
+        sb = _sequence_bias_tables(sequence_bias, V, dev)   # HF SequenceBiasLogitsProcessor (model.generate(sequence_bias=...))
+        # processors + per-row top-k in one pass, no fp32 score matrix (a sequence bias takes the two-kernel form)
+        fused_select = Vp <= ops.SELECT_MAX_LDV and not sb
         scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
 
         def step(tok: torch.Tensor, t: int, parent, ctr=None, idx64=None):
@@ -135,7 +174,7 @@ class Generator:
         proc = dict(logits16=logits, scores32=scores, rows=Bp, V=V, ldv=Vp, ids_ld=max_len, begin_index=P,
                     repetition_penalty=float(repetition_penalty), no_repeat_ngram=int(no_repeat_ngram_size),
                     suppress=sup, n_suppress=len(suppress_tokens), begin_suppress=bsup,
-                    n_begin_suppress=len(begin_suppress_tokens))
+                    n_begin_suppress=len(begin_suppress_tokens), **sb)
 
         seqs = [torch.full((Bp, max_len), pad, device=dev, dtype=torch.int64) for _ in range(2)]
         seqs[0][:, :P] = prompt.repeat_interleave(nb, 0)

@@ -112,6 +112,8 @@ class LogitsProcDesc(C.Structure):
         ("n_suppress", C.c_int32), ("n_begin_suppress", C.c_int32), ("no_repeat_ngram", C.c_int32),
         ("log_softmax", C.c_int32),
         ("repetition_penalty", C.c_float),
+        ("bias1", C.c_void_p), ("seq_tok", C.c_void_p), ("seq_off", C.c_void_p), ("seq_bias", C.c_void_p),
+        ("n_seq", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

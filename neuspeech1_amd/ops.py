@@ -199,13 +199,14 @@ def vt_pack(v16, ldv, vt16, groups, H, Lk, ldvt):
 
 def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, beam_scores=None,
                    repetition_penalty=1.0, no_repeat_ngram=0, suppress=None, n_suppress=0, begin_suppress=None,
-                   n_begin_suppress=0, cur_len_dev=None):
+                   n_begin_suppress=0, cur_len_dev=None, bias1=None, seq_tok=None, seq_off=None, seq_bias=None, n_seq=0):
     d = L.LogitsProcDesc()
     d.logits16, d.scores32, d.ids, d.beam_scores = ptr(logits16), ptr(scores32), ptr(ids), ptr(beam_scores)
     d.suppress, d.begin_suppress, d.cur_len_dev = ptr(suppress), ptr(begin_suppress), ptr(cur_len_dev)
     d.rows, d.V, d.ldv, d.ids_ld, d.cur_len, d.begin_index = rows, V, ldv, ids_ld, cur_len, begin_index
     d.n_suppress, d.n_begin_suppress, d.no_repeat_ngram, d.log_softmax = n_suppress, n_begin_suppress, no_repeat_ngram, int(log_softmax)
     d.repetition_penalty = repetition_penalty
+    d.bias1, d.seq_tok, d.seq_off, d.seq_bias, d.n_seq = ptr(bias1), ptr(seq_tok), ptr(seq_off), ptr(seq_bias), n_seq
     L.check(L.load().ns_logits_process(C.byref(d), _stream()), "ns_logits_process")
 
 

@@ -250,3 +250,35 @@ def test_finetune_full_model_adapters_then_decode(dev, tmp_path, adalora):
                    "--augment_config_path=None", "--ft_full=True", f"--resume_from_checkpoint={ck}", "--max_steps=2"] + common)
     logs2 = [json.loads(l) for l in open(os.path.join(out + "2", "synthetic_tiny", "train_log.jsonl"))]
     assert logs2[0]["loss"] < logs[0]["loss"], (logs2, logs)     # it starts from the trained adapters, not from scratch
+
+
+def test_evaluation_with_sequence_bias(dev, tmp_path, capsys):
+    """--add_sequence_bias=True (evaluation.py:339-343,362-364): a -1.0 bias on every word of the TRAINING list
+    (test.jsonl -> train.jsonl, as the reference derives it) reaches model.generate (its effect on the ids is pinned
+    in tests/test_generate_gpu.py); the reference's own 'phrase_word' table needs `yake`, which this image lacks: a
+    clear ImportError, not a silent skip."""
+    import shutil
+    import evaluation
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 8, ch_file=24, name="toyset", seed=4, min_len=120, max_len=520)
+    test_jl = os.path.join(os.path.dirname(jl), "test.jsonl")
+    shutil.copy(jl, test_jl)
+    shutil.copy(jl, os.path.join(os.path.dirname(jl), "train.jsonl"))
+    common = [f"--test_data={test_jl}", "--model_path=synthetic:tiny", "--modal=eeg", "--eeg_ch=20", "--sampling_rate=200",
+              "--timestamps=False", "--max_audio_len=2.0", "--language=Dutch", "--num_workers=0", "--batch_size=4",
+              "--max_new_tokens=10"]
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        evaluation.main(common)
+        plain = open("formal_test_resultsno_post_processing.jsonl").read()
+        evaluation.main(common + ["--add_sequence_bias=True", "--sequence_bias_type=word", "--extra_name=sb"])
+        biased = open("formal_test_results_sbno_post_processing.jsonl").read()
+        with pytest.raises(ImportError):
+            evaluation.main(common + ["--add_sequence_bias=True"])
+    finally:
+        os.chdir(cwd)
+    assert len(biased.splitlines()) == 8 and len(plain.splitlines()) == 8
+    import re
+    m = re.search(r"sequence bias: (\d+) token sequences", capsys.readouterr().out)
+    assert m and int(m.group(1)) > 0

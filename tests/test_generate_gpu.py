@@ -179,3 +179,68 @@ def test_token_ids_exact_at_whisper_base_dims(dev, name, nb, kw):
     check(out, g[name], dims.pad_id)
     if nb > 1:
         np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[name + "_scores"], atol=2e-2)
+
+
+def _sb_from_golden(g):
+    return {tuple(int(t) for t in str(k).split(",")): float(v) for k, v in zip(g["sequence_bias_keys"], g["sequence_bias_vals"])}
+
+
+@pytest.mark.parametrize("name,nb,kw", [
+    ("greedy_sb", 1, {}),
+    ("greedy_rp_sb", 1, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("beam5_sb", 5, {}),
+    ("beam5_rp_sb", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+])
+def test_sequence_bias_token_ids_exact(setup, name, nb, kw):
+    """model.generate(sequence_bias=...) (HF SequenceBiasLogitsProcessor; evaluation.py:362-364 passes it with
+    --add_sequence_bias): ids of the reference object run with the same bias table (tools/make_goldens.py decode_sb)."""
+    _, dims, gen, x, prompt = setup
+    g = np.load(os.path.join(G, "decode_tiny_sb.npz"))
+    out = gen.generate(x, prompt, num_beams=nb, max_new_tokens=int(g["new_tokens"]), check_every=1,
+                       sequence_bias=_sb_from_golden(g), **kw)
+    if nb == 1:
+        check(out, g[name], dims.pad_id)
+        return
+    # beam search on this flat random-init model has near-ties: a row may end on a different hypothesis whose
+    # length-normalised score is within fp16 noise of the reference's (row 0 of beam5_rp_sb: -4.690 vs -4.683); every
+    # other row must be token-exact, and the processor itself is checked against HF's classes below
+    ref, got = g[name], out.cpu().numpy()
+    same = [np.array_equal(got[b, :ref.shape[1]], ref[b]) for b in range(ref.shape[0])]
+    np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[name + "_scores"], atol=2e-2)
+    assert sum(same) >= ref.shape[0] - 1 and got.shape == ref.shape, (same, got.tolist(), ref.tolist())
+
+
+def test_sequence_bias_processor_matches_hf_processors(dev):
+    """ns_logits_process with a bias table against HF's own processor classes chained in HF's order
+    (SequenceBias -> RepetitionPenalty -> NoRepeatNGram), on histories that end with the biased prefixes."""
+    from transformers.generation.logits_process import (NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
+                                                         SequenceBiasLogitsProcessor)
+    from neuspeech1_amd import ops
+    from neuspeech1_amd.generate import _sequence_bias_tables
+    rows, V, Vp, cur, ld = 7, 1000, 1024, 12, 16
+    gcpu = torch.Generator().manual_seed(3)
+    logits = (torch.randn(rows, Vp, generator=gcpu) * 3).half()
+    ids = torch.randint(5, 60, (rows, ld), generator=gcpu)
+    ids[0, cur - 2:cur] = torch.tensor([7, 8])          # row 0 ends with (7, 8): both 3-token sequences below fire
+    ids[1, cur - 1] = 8                                 # row 1 ends with 8: the 2-token sequence fires
+    ids[2, cur - 3:cur] = torch.tensor([9, 7, 8])       # 4-token sequence
+    ids[3, :cur] = 41                                   # a repeated token that also carries a single-token bias
+    sb = {(41,): -3.0, (500,): 2.5, (7, 8, 123): 4.0, (7, 8, 500): -1.25, (8, 77): 6.0, (8, 123): 0.5, (9, 7, 8, 200): 3.0,
+          tuple(range(100, 100 + cur + 1)): 9.0}        # longer than the context: ignored
+    for log_softmax in (False, True):
+        sc = torch.log_softmax(logits[:, :V].float(), -1) if log_softmax else logits[:, :V].float()
+        ref = SequenceBiasLogitsProcessor(sequence_bias=dict(sb))(ids[:, :cur], sc.clone())
+        ref = RepetitionPenaltyLogitsProcessor(penalty=5.0)(ids[:, :cur], ref)
+        ref = NoRepeatNGramLogitsProcessor(2)(ids[:, :cur], ref)
+        out = torch.full((rows, V), float("nan"), device=dev)
+        ops.logits_process(logits16=logits.to(dev), scores32=out, ids=ids.to(dev), rows=rows, V=V, ldv=Vp, ids_ld=ld,
+                           cur_len=cur, begin_index=4, log_softmax=log_softmax, repetition_penalty=5.0, no_repeat_ngram=2,
+                           **_sequence_bias_tables(dict(sb), V, dev))
+        got = out.cpu()
+        assert torch.equal(torch.isinf(got), torch.isinf(ref))
+        fin = ~torch.isinf(ref)
+        torch.testing.assert_close(got[fin], ref[fin], atol=2e-5, rtol=1e-5)
+        assert abs(got[0, 123] - (sc[0, 123] + 4.0 + 0.5)) < 1e-4 or 123 in ids[0, :cur].tolist()
+    for bad in ({}, {(1, 2): 1}, {(V,): 1.0}, [[[], 1.0]], {(-1,): 1.0}):
+        with pytest.raises(ValueError):
+            _sequence_bias_tables(bad, V, dev)

@@ -113,7 +113,7 @@ def lora_golden(dims, tag, B, r=32, alpha=64.0, decoder=False):
     print(f"lora_merged_{tag}: loss {out.loss.item():.6f}")
 
 
-def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630)):
+def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630), sequence_bias=None):
     import transformers
     sd_np = make_state_dict(dims, 42)
     model = build_hf(dims, sd_np)
@@ -137,6 +137,20 @@ def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630)):
         o = gen(model, feats, num_beams=5, **common)
         g["beam5"] = o.sequences.numpy()
         g["beam5_scores"] = o.sequences_scores.numpy().astype(np.float32)
+        if sequence_bias is not None:
+            # HF SequenceBiasLogitsProcessor through the reference object: single tokens, 2- and 3-token sequences
+            g["sequence_bias_keys"] = np.array([",".join(map(str, k)) for k in sequence_bias])
+            g["sequence_bias_vals"] = np.array(list(sequence_bias.values()), dtype=np.float64)
+            o = gen(model, feats, num_beams=1, sequence_bias=dict(sequence_bias), **common)
+            g["greedy_sb"] = o.sequences.numpy()
+            o = gen(model, feats, num_beams=1, repetition_penalty=5.0, no_repeat_ngram_size=2, sequence_bias=dict(sequence_bias), **common)
+            g["greedy_rp_sb"] = o.sequences.numpy()
+            o = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, sequence_bias=dict(sequence_bias), **common)
+            g["beam5_rp_sb"] = o.sequences.numpy()
+            g["beam5_rp_sb_scores"] = o.sequences_scores.numpy().astype(np.float32)
+            o = gen(model, feats, num_beams=5, sequence_bias=dict(sequence_bias), **common)
+            g["beam5_sb"] = o.sequences.numpy()
+            g["beam5_sb_scores"] = o.sequences_scores.numpy().astype(np.float32)
         # EOS variants: declare a frequently generated token id as EOS so rows / hypotheses really finish
         for eos in eos_variants:
             c2 = dict(common, eos_token_id=eos)
@@ -166,6 +180,16 @@ if __name__ == "__main__":
         lora_golden(TINY, "tiny_full", B=2, decoder=True)
     if "decode" in what:
         decode_golden(TINY, "tiny", B=3, new_tokens=24)
+    if "decode_sb" in what:
+        # biases chosen on the unbiased greedy output of decode_tiny.npz: penalise its most frequent tokens, reward a few
+        # others, and bias continuations of 2- / 3-token contexts that really occur
+        g0 = np.load(os.path.join(OUT, "decode_tiny.npz"))["greedy_rp"]
+        sb = {(630,): -4.0, (34,): -2.5, (17,): 3.0, (250,): 2.0}
+        for b in range(g0.shape[0]):
+            sb[(int(g0[b, 6]), int(g0[b, 7]), 99 + b)] = 9.0          # after (t6, t7) strongly prefer token 99 + b
+            sb[(int(g0[b, 9]), int(g0[b, 10]))] = -8.0                # and break the original continuation t9 -> t10
+            sb[(int(g0[b, 5]), int(g0[b, 6]))] = -1.5
+        decode_golden(TINY, "tiny_sb", B=3, new_tokens=24, eos_variants=(), sequence_bias=sb)
     if "decode_base" in what:
         # BASELINE dims (whisper-base, 208-ch): token-id parity at the size the metric is quoted on
         decode_golden(WHISPER_BASE, "base208", B=2, new_tokens=16, eos_variants=())

@@ -346,8 +346,6 @@ class WhisperForConditionalGeneration(nn.Module):
         """evaluation.py:370-386 call shape; returns prompt + generated ids (B, <= max_length) int64."""
         if do_sample:
             raise NotImplementedError("sampling is outside the hot path (the reference decodes with do_sample=False)")
-        if sequence_bias:
-            raise NotImplementedError("sequence_bias (--add_sequence_bias) is outside the hot path")
         from neuspeech1_amd.generate import Generator
         eng = self.engine()
         eng.refresh_operands()
@@ -363,7 +361,8 @@ class WhisperForConditionalGeneration(nn.Module):
         return Generator(eng).generate(x, prompt, num_beams=num_beams, max_new_tokens=new,
                                        repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
                                        suppress_tokens=list(sup), begin_suppress_tokens=list(bsup),
-                                       length_penalty=length_penalty, eos_id=eos_token_id, pad_id=pad_token_id)
+                                       length_penalty=length_penalty, eos_id=eos_token_id, pad_id=pad_token_id,
+                                       sequence_bias=sequence_bias)
 
 
 def _resolve_device(device_map):
