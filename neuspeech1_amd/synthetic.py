@@ -45,6 +45,13 @@ class SyntheticTokenizer:
             key = {"english": "<|en|>", "en": "<|en|>", "dutch": "<|nl|>", "nl": "<|nl|>"}.get(str(language).lower())
             self.lang = key or "<|en|>"
 
+    @property
+    def prefix_tokens(self):
+        """WhisperTokenizer.prefix_tokens with predict_timestamps=False (what the reference's processors have: their
+        `no_timestamps=` keyword is not a tokenizer argument): sot, language, task, <|notimestamps|>"""
+        s = self.special
+        return [s["<|startoftranscript|>"], s[self.lang], s["<|transcribe|>"], s["<|notimestamps|>"]]
+
     def encode_text(self, text: str):
         ids = [(ord(c) * 31 + 7) % self.n_text for c in text]
         s = self.special
@@ -74,7 +81,7 @@ class SyntheticProcessor:
         self.feature_extractor = None
 
     def __call__(self, text=None, **_):
-        return {"input_ids": self.tokenizer.encode_text(text)}
+        return _Batch(input_ids=self.tokenizer.encode_text(text))
 
     def batch_decode(self, ids, skip_special_tokens=True):
         return self.tokenizer.batch_decode(ids, skip_special_tokens)
@@ -96,8 +103,13 @@ def write_synthetic_dataset(root: str, n: int, ch_file: int = 224, name: str = "
         x = np.clip(0.35 * rng.standard_normal((ch_file, L)), -1, 1)
         path = os.path.join(root, name, f"sample_{i:05d}.npy")
         np.save(path, x)
-        sent = " ".join(rng.choice(words, size=int(rng.integers(3, 9))))
-        rows.append({"eeg": {"path": path}, "sentence": sent, "language": "English", "duration": L / 200.0})
+        chosen = [str(w) for w in rng.choice(words, size=int(rng.integers(3, 9)))]
+        sent = " ".join(chosen)
+        # per-sentence / per-word timing records for --timestamps=True (finetune.py's default): words spread over the signal
+        step = (L / 200.0) / (len(chosen) + 1)
+        wrec = [{"start": round(step * (k + 0.5), 2), "end": round(step * (k + 1.4), 2), "word": w} for k, w in enumerate(chosen)]
+        rows.append({"eeg": {"path": path}, "sentence": sent, "language": "English", "duration": L / 200.0,
+                     "sentences": [{"start": wrec[0]["start"], "end": wrec[-1]["end"], "text": sent, "words": wrec}]})
     jl = os.path.join(root, f"{name}_data.jsonl")
     with open(jl, "w") as f:
         for r in rows:

@@ -4,6 +4,7 @@ repetition penalty / no-repeat-ngram, and the teacher-forced branch) on a synthe
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -282,3 +283,20 @@ def test_evaluation_with_sequence_bias(dev, tmp_path, capsys):
     import re
     m = re.search(r"sequence bias: (\d+) token sequences", capsys.readouterr().out)
     assert m and int(m.group(1)) > 0
+
+
+def test_finetune_with_default_timestamp_labels_at_whisper_base_dims(dev, tmp_path):
+    """The reference's training recipes leave --timestamps at its default True: labels carry <|t|> tokens (ids up to
+    51864, so this runs on the whisper-base vocabulary), 208 gwilliams channels through the on-GPU feed."""
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 6, ch_file=224, name="gwilliams", seed=5, min_len=900, max_len=2400)
+    out = str(tmp_path / "out")
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:base", f"--output_dir={out}",
+                   "--modal=eeg", "--eeg_ch=208", "--sampling_rate=200", "--orig_sample_rate=200", "--max_audio_len=30",
+                   "--language=English", "--num_workers=0", "--use_adalora=False", "--fp16=True", "--num_train_epochs=1",
+                   "--per_device_train_batch_size=2", "--per_device_eval_batch_size=2", "--logging_steps=1",
+                   "--eval_steps=100", "--save_steps=100", "--warmup_steps=0", "--learning_rate=1e-3",
+                   "--augment_config_path=configs/augmentation1.json", "--max_steps=3"])
+    logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_base", "train_log.jsonl"))]
+    assert len(logs) == 3 and all(np.isfinite(l["loss"]) for l in logs) and logs[-1]["loss"] < logs[0]["loss"] + 0.5, logs

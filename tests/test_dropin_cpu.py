@@ -48,12 +48,49 @@ def test_reader_and_collator_match_reference_outputs(tmp_path):
         assert np.array_equal(batch["labels"].numpy(), g[f"{name}.batch_labels"])
 
 
+def test_timestamp_labels_match_reference_reader(tmp_path):
+    """--timestamps=True is finetune.py's DEFAULT (the training recipes of the reference do not override it): labels are
+    <|sot|> <|lang|> <|task|> then <|t_start|> tokens <|t_end|> per sentence / per word on the 0.02 s grid
+    (reference reader :347-400).  Ids of the reference's own reader on the same records (tests/golden/reader.npz)."""
+    from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding
+    from utils.reader import CustomDataset
+    g = np.load(os.path.join(G, "reader.npz"))
+    rows = json.loads(str(g["ts.rows"]))
+    proc = SyntheticProcessor(WHISPER_BASE)
+    rng = np.random.default_rng(99)
+    for k, r in enumerate(rows):        # the signal side of the reader is pinned by the test above; here: the labels
+        p = str(tmp_path / f"gwilliams_ts{k}.npy")
+        np.save(p, rng.standard_normal((224, 1200 + 300 * k)))
+        r["eeg"]["path"] = p
+    jl = str(tmp_path / "ts.jsonl")
+    with open(jl, "w") as f:
+        for r in rows:
+            f.write(json.dumps(r) + "\n")
+    for level in ("sentences", "words"):
+        kw = dict(data_list_path=jl, processor=proc, modal="eeg", modal_ch=208, mode="val", level=level, sample_rate=200,
+                  orig_sample_rate=200, language="English", timestamps=True, min_duration=0.5, max_duration=30)
+        ds = CustomDataset(**kw)
+        items = [ds[i] for i in range(len(ds))]
+        for i, it in enumerate(items):
+            assert list(it["labels"]) == g[f"ts.{level}.{i}.labels"].tolist(), (level, i)
+            assert it["input_features"][0].shape == (208, 6000)
+        batch = DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)
+        assert np.array_equal(batch["labels"].numpy(), g[f"ts.{level}.batch_labels"])
+        # the on-GPU feed's raw mode carries the same labels
+        raw = CustomDataset(raw_signals=True, **kw)
+        assert [list(raw[i]["labels"]) for i in range(len(raw))] == [list(it["labels"]) for it in items]
+    # odd centiseconds: starts round up, ends round down to the 0.02 s grid
+    ds = CustomDataset(**kw)
+    assert ds._time_token(0.13, True) == ds.timestamp_begin + 7 and ds._time_token(0.13, False) == ds.timestamp_begin + 6
+    assert ds._time_token(0.12, True) == ds._time_token(0.12, False) == ds.timestamp_begin + 6
+
+
 def test_reader_refuses_out_of_path_modes(tmp_path):
     from utils.reader import CustomDataset
     proc = SyntheticProcessor(WHISPER_BASE)
     jl = str(tmp_path / "x.jsonl")
     open(jl, "w").write("")
-    for kw in (dict(modal="speech"), dict(combine_sentences=True), dict(timestamps=True)):
+    for kw in (dict(modal="speech"), dict(combine_sentences=True), dict(split_sentences=True)):
         with pytest.raises(NotImplementedError):
             CustomDataset(data_list_path=jl, processor=proc, **{"modal": "eeg", **kw})
 

@@ -260,6 +260,40 @@ def reader_golden():
             out[f"{name}.batch_dtype"] = np.array(str(batch["input_features"].dtype))
             out[f"{name}.batch_sum"] = np.float64(batch["input_features"].double().sum().item())
             out[f"{name}.batch_labels"] = batch["labels"].numpy()
+        # timestamp labels (finetune.py's default --timestamps=True; reference reader :347-400): sentence and word level
+        rng = np.random.default_rng(99)
+        rows = []
+        for k in range(4):
+            n = 1200 + 300 * k
+            p = os.path.join(td, "gwilliams", f"ts{k}.npy")
+            np.save(p, rng.standard_normal((224, n)))
+            sents, t0 = [], 0.0
+            for si in range(1 + k % 3):
+                words, t = [], t0 + float(rng.integers(0, 50)) / 100
+                for wi in range(2 + si):
+                    dur = float(rng.integers(5, 60)) / 100           # odd and even centiseconds both occur
+                    words.append({"start": round(t, 2), "end": round(t + dur, 2), "word": f"w{k}{si}{wi}"})
+                    t += dur + float(rng.integers(0, 9)) / 100
+                sents.append({"start": words[0]["start"], "end": words[-1]["end"], "text": " ".join(w["word"] for w in words),
+                              "words": words})
+                t0 = t
+            rows.append({"eeg": {"path": p}, "sentence": " ".join(s_["text"] for s_ in sents), "sentences": sents,
+                         "language": "English", "duration": n / 200})
+        jl = os.path.join(td, "ts.jsonl")
+        with open(jl, "w") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+        out["ts.rows"] = np.array(json.dumps(rows))
+        for level in ("sentences", "words"):
+            ds = ref_reader.CustomDataset(data_list_path=jl, processor=proc, modal="eeg", modal_ch=208, mode="val", level=level,
+                                          sample_rate=200, orig_sample_rate=200, language="English", timestamps=True,
+                                          min_duration=0.5, max_duration=30)
+            items = [ds[i] for i in range(len(ds))]
+            for i, it in enumerate(items):
+                out[f"ts.{level}.{i}.labels"] = np.array(it["labels"])
+                out[f"ts.{level}.{i}.sum"] = np.float64(it["input_features"][0].sum())
+            batch = ref_data.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)
+            out[f"ts.{level}.batch_labels"] = batch["labels"].numpy()
     np.savez_compressed(os.path.join(OUT, "reader.npz"), **out)
     print("reader golden:", len(out), "entries")
     for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:

@@ -2,9 +2,10 @@
 
 Kept: the constructor signature, `.data_list`, `__len__`, `__getitem__`, the dataset-specific channel slice
 (schoffelen [28:301], gwilliams [:208]), channel zero-padding, time crop / right zero-padding to
-max_duration*sample_rate, timestamp-free labels = processor(text=...).input_ids and the <|nocaptions|> fallback.
-Out of the hot path and therefore refused loudly: modal='speech', combine_sentences, split_sentences, the noise /
-shift augmentations (their shipped probabilities are 0.0, configs/augmentation1.json) and timestamp labels.
+max_duration*sample_rate, timestamp-free labels = processor(text=...).input_ids, timestamp labels (finetune.py's default
+--timestamps=True: <|t_start|> text <|t_end|> per sentence or word on the 0.02 s grid) and the <|nocaptions|> fallback.
+Out of the hot path and therefore refused loudly: modal='speech', combine_sentences, split_sentences and the noise /
+shift augmentations (their shipped probabilities are 0.0, configs/augmentation1.json).
 """
 import copy
 import json
@@ -36,8 +37,6 @@ class CustomDataset(Dataset):
             raise NotImplementedError("only modal='eeg' (MEG/EEG arrays) is on the MI355X hot path")
         if combine_sentences or split_sentences:
             raise NotImplementedError("combine_sentences / split_sentences are outside the hot path")
-        if timestamps:
-            raise NotImplementedError("timestamp labels are outside the hot path (every reference recipe uses --timestamps=False)")
         self.data_list_path, self.processor, self.mode, self.level = data_list_path, processor, mode, level
         self.signal_sample_rate, self.orig_sample_rate = sample_rate, orig_sample_rate
         self.language, self.filter_dataset, self.timestamps = language, filter_dataset, timestamps
@@ -75,13 +74,15 @@ class CustomDataset(Dataset):
         path = row[self.modal]["path"]
         assert path is not None
         lo, hi = self.channel_slice(path)
+        # timestamp labels are built from the per-sentence records (reference :265); finetune.py defaults to them
+        transcript = row["sentences"] if self.timestamps else row["sentence"]
         if self.raw_signals:
             from neuspeech1_amd.feed import RawSignal
-            return RawSignal(path, lo, hi, self.modal_ch), self.signal_sample_rate, row["sentence"], row.get("language")
+            return RawSignal(path, lo, hi, self.modal_ch), self.signal_sample_rate, transcript, row.get("language")
         sample = np.load(path)[lo:hi]                # (>=ch, n) float64
         if self.modal_ch > sample.shape[0]:
             sample = self.pad_sample_ch(sample)
-        return sample, self.signal_sample_rate, row["sentence"], row.get("language")
+        return sample, self.signal_sample_rate, transcript, row.get("language")
 
     def channel_slice(self, path):
         """dataset-specific channel rows (reference :282-290)"""
@@ -95,7 +96,8 @@ class CustomDataset(Dataset):
         sample, _, transcript, language = self._get_list_data(idx)
         self.processor.tokenizer.set_prefix_tokens(language=language if language is not None else self.language)
         if len(transcript) > 0:
-            return {"input_features": self.padding_sample(sample), "labels": self.process_transcript(transcript)}
+            labels = self._load_timestamps_transcript(transcript) if self.timestamps else self.process_transcript(transcript)
+            return {"input_features": self.padding_sample(sample), "labels": labels}
         return {"input_features": self.padding_sample(sample),
                 "labels": [self.startoftranscript, self.nocaptions, self.endoftext]}
 
@@ -116,6 +118,37 @@ class CustomDataset(Dataset):
             return sample
         assert sample.shape[0] < self.modal_ch, "sample channel must be less than modal channel"
         return np.pad(sample, pad_width=((0, self.modal_ch - sample.shape[0]), (0, 0)))
+
+    # ---- timestamp labels (reference :347-400): <|sot|> <|lang|> <|task|> then per segment
+    #      <|t_start|> text tokens <|t_end|>, times on Whisper's 0.02 s grid, <|endoftext|> last
+    def _time_token(self, t, is_start):
+        if round(t * 100) % 2 != 0:
+            t = t + 0.01 if is_start else t - 0.01
+        return self.timestamp_begin + round(t * 100) // 2
+
+    def _segment(self, labels, start, end, text):
+        s_tok, e_tok = self._time_token(start, True), self._time_token(end, False)
+        label = self.processor(text=text).input_ids[4:-1]
+        if max(label) > 51865 or s_tok > 51865 or e_tok > 51865:
+            print(f"OOV text {text} label {label} start {start}->{s_tok} end {end}->{e_tok}\n")
+            raise ValueError
+        labels.extend([s_tok])
+        labels.extend(label)
+        labels.extend([e_tok])
+
+    def _load_timestamps_transcript(self, transcript):
+        assert isinstance(transcript, list), f"transcript must be a list, got {type(transcript)}"
+        labels = list(self.processor.tokenizer.prefix_tokens[:3])
+        if self.level == "sentences":
+            for t in transcript:
+                self._segment(labels, t["start"], t["end"], t["text"])
+        elif self.level == "words":
+            for t in transcript:
+                for w in t["words"]:
+                    self._segment(labels, w["start"], w["end"], w["word"])
+        else:
+            raise NotImplementedError
+        return labels + [self.endoftext]
 
     def process_transcript(self, transcript):
         return self.processor(text=transcript)["input_ids"]
