@@ -6,7 +6,7 @@ same flags, same defaults, same outputs), driven by the HIP engine instead of HF
 
 Per step (reference finetune.py:231-281 -> HF Trainer inner loop): forward, backward, RCCL all-reduce (AVG) of the
 flat trainable-gradient buffer overlapped with backward, GradScaler unscale + inf check, clip to 1.0, AdamW, linear
-warmup/decay; eval = loss only; a checkpoint is written only when the eval loss is the best so far
+warmup/decay; eval = loss only; a checkpoint is written at a save step only while the latest recorded eval loss is the best so far
 (utils/callback.py:11-32) plus `checkpoint-final` at the end.
 """
 import argparse
@@ -164,6 +164,15 @@ class DevicePrefetcher:
             yield cur
 
 
+def rotate_checkpoints(output_dir, keep):
+    """HF Trainer's save_total_limit: only the `keep` newest checkpoint-<step> directories stay"""
+    import re
+    import shutil
+    steps = sorted(int(m.group(1)) for m in (re.fullmatch(r"checkpoint-(\d+)", n) for n in os.listdir(output_dir)) if m)
+    for st in steps[:-keep] if keep > 0 else []:
+        shutil.rmtree(os.path.join(output_dir, f"checkpoint-{st}"), ignore_errors=True)
+
+
 def grouped(iterable, n):
     """lists of up to n consecutive items (the last group of an epoch may be shorter, as in HF Trainer)"""
     buf = []
@@ -287,7 +296,7 @@ def main(argv=None):
         from neuspeech1_amd.feed import SignalFeed
         feed = SignalFeed(whisper.device, eng.dims.ch, eng.dims.T, eng.dims.ch_pad, threads=max(2, args.num_workers))
 
-    step, best, t_log, n_log = 0, float("inf"), time.time(), 0
+    step, eval_history, t_log, n_log = 0, [], time.time(), 0
     log_path = os.path.join(output_dir, "train_log.jsonl")
     done = False
     for epoch in range(args.num_train_epochs):
@@ -315,14 +324,18 @@ def main(argv=None):
                 with open(log_path, "a") as f:
                     f.write(json.dumps(rec) + "\n")
                 t_log, n_log = time.time(), 0
+            # SavePeftModelCallback.on_step_end (utils/callback.py:12-22) decides BEFORE this step's evaluation: save at a
+            # multiple of save_steps iff the most recent eval loss on record is the minimum of all recorded ones
+            should_save = step % args.save_steps == 0 and len(eval_history) > 0 and eval_history[-1] == min(eval_history)
             if step % args.eval_steps == 0:
                 ev = evaluate_loss(whisper, test_dataset, data_collator, args.per_device_eval_batch_size, rank, world,
                                    args.num_workers)
+                eval_history.append(ev)
                 if rank == 0:
                     print(json.dumps({"step": step, "eval_loss": round(ev, 5)}), flush=True)
-                    if ev < best and step % args.save_steps == 0:   # save only on a new best eval loss
-                        model.save_pretrained(os.path.join(output_dir, f"checkpoint-{step}"))
-                best = min(best, ev)
+            if should_save and rank == 0:
+                model.save_pretrained(os.path.join(output_dir, f"checkpoint-{step}"))
+                rotate_checkpoints(output_dir, keep=5)          # save_total_limit=5 (finetune.py:245)
             if step >= total_steps:
                 done = True
                 break

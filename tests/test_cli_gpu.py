@@ -29,6 +29,10 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
     assert os.path.exists(os.path.join(ck, "adapter_config.json")) and os.path.exists(os.path.join(ck, "adapter_model.safetensors"))
     logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_tiny", "train_log.jsonl"))]
     assert len(logs) == 6 and logs[-1]["loss"] < logs[0]["loss"], logs
+    # the reference's callback decides a save from the eval losses recorded BEFORE the step's own evaluation
+    # (utils/callback.py:12-22): nothing at step 2 (no eval on record yet), checkpoint-4 on the strength of eval@2
+    assert not os.path.exists(os.path.join(out, "synthetic_tiny", "checkpoint-2"))
+    assert os.path.exists(os.path.join(out, "synthetic_tiny", "checkpoint-4", "adapter_model.safetensors"))
     from safetensors.torch import load_file
     sd = load_file(os.path.join(ck, "adapter_model.safetensors"))
     if adalora:   # peft's AdaLoRA layout: bare parameters, rank 12, E moved off its zero init

@@ -95,6 +95,15 @@ def test_reader_refuses_out_of_path_modes(tmp_path):
             CustomDataset(data_list_path=jl, processor=proc, **{"modal": "eeg", **kw})
 
 
+def test_checkpoint_rotation_keeps_the_newest_five(tmp_path):
+    import finetune
+    for st in (1000, 3000, 2000, 12000, 7000, 9000, 11000):
+        os.makedirs(tmp_path / f"checkpoint-{st}")
+    os.makedirs(tmp_path / "checkpoint-final")
+    finetune.rotate_checkpoints(str(tmp_path), keep=5)      # save_total_limit=5, finetune.py:245
+    assert sorted(os.listdir(tmp_path)) == sorted(["checkpoint-final"] + [f"checkpoint-{s_}" for s_ in (3000, 7000, 9000, 11000, 12000)])
+
+
 def test_add_arguments_bool_and_none_parsing():
     from utils.utils import add_arguments
     p = argparse.ArgumentParser()
