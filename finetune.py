@@ -107,15 +107,33 @@ def shard_indices(n, epoch, rank, world, seed=42, shuffle=True):
     return idx[rank:total:world]
 
 
-def evaluate_loss(model, dataset, collator, batch_size, rank, world, num_workers):
+def evaluate_loss(model, dataset, collator, batch_size, rank, world, num_workers, feed=None):
+    """eval_loss as HF Trainer reports it: the batch losses weighted by their sample counts (evaluation_loop repeats
+    each batch loss batch_size times before averaging), ranks sharded like DistributedSampler without shuffling.
+    With `feed` (SignalFeed) the recordings take the on-GPU path, the next batch staged while this one runs."""
     eng = model.engine()
     idx = shard_indices(len(dataset), 0, rank, world, shuffle=False)
-    tot, cnt = 0.0, 0
-    for i in range(0, len(idx), batch_size):
-        batch = collator([dataset[j] for j in idx[i:i + batch_size]])
-        loss, _ = eng.forward(batch["input_features"].to(model.device), batch["labels"].to(model.device), train=False)
-        tot += loss.item()
-        cnt += 1
+    chunks = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
+    was_raw = dataset.raw_signals
+    dataset.raw_signals = feed is not None
+    try:
+        def produce(ch):
+            batch = collator([dataset[j] for j in ch])
+            x = batch["input_features"]
+            return (feed.submit(x) if feed is not None else x.to(model.device)), batch["labels"].to(model.device)
+        tot, cnt = 0.0, 0
+        nxt = produce(chunks[0]) if chunks else None
+        for k, ch in enumerate(chunks):
+            (x, y), nxt = nxt, (produce(chunks[k + 1]) if k + 1 < len(chunks) else None)
+            if feed is not None:
+                x = x.result()
+            loss, _ = eng.forward(x, y, train=False)
+            if feed is not None:
+                x.release()
+            tot += loss.item() * len(ch)
+            cnt += len(ch)
+    finally:
+        dataset.raw_signals = was_raw
     t = torch.tensor([tot, cnt], device=model.device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t)
@@ -329,7 +347,7 @@ def main(argv=None):
             should_save = step % args.save_steps == 0 and len(eval_history) > 0 and eval_history[-1] == min(eval_history)
             if step % args.eval_steps == 0:
                 ev = evaluate_loss(whisper, test_dataset, data_collator, args.per_device_eval_batch_size, rank, world,
-                                   args.num_workers)
+                                   args.num_workers, feed=feed)
                 eval_history.append(ev)
                 if rank == 0:
                     print(json.dumps({"step": step, "eval_loss": round(ev, 5)}), flush=True)
