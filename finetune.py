@@ -317,6 +317,7 @@ def main(argv=None):
     step, eval_history, t_log, n_log = 0, [], time.time(), 0
     log_path = os.path.join(output_dir, "train_log.jsonl")
     done = False
+    loss_sum, loss_cnt = torch.zeros((), device=whisper.device), 0
     for epoch in range(args.num_train_epochs):
         idx = shard_indices(len(train_dataset), epoch, rank, world)
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(train_dataset, idx), batch_size=B, shuffle=False,
@@ -331,17 +332,20 @@ def main(argv=None):
                 loss = torch.stack(micro).mean()
             step += 1
             n_log += sum(x.shape[0] for x, _ in group)
+            loss_sum, loss_cnt = loss_sum + loss.detach().reshape(()).float(), loss_cnt + 1   # stays on the device
             for x, _ in group:
                 if hasattr(x, "release"):
                     x.release()         # the step reading this staged batch is enqueued: its slot may be refilled
             if step % args.logging_steps == 0 and rank == 0:
                 dt = time.time() - t_log
-                rec = {"step": step, "epoch": round(step / steps_per_epoch, 3), "loss": round(loss.item(), 5),
+                # HF Trainer logs the MEAN training loss of the steps since the previous log line
+                rec = {"step": step, "epoch": round(step / steps_per_epoch, 3), "loss": round((loss_sum / loss_cnt).item(), 5),
                        "samples_per_s": round(world * n_log / dt, 2), "loss_scale": eng.loss_scale_dev.item()}
                 print(json.dumps(rec), flush=True)
                 with open(log_path, "a") as f:
                     f.write(json.dumps(rec) + "\n")
                 t_log, n_log = time.time(), 0
+                loss_sum, loss_cnt = torch.zeros((), device=whisper.device), 0
             # SavePeftModelCallback.on_step_end (utils/callback.py:12-22) decides BEFORE this step's evaluation: save at a
             # multiple of save_steps iff the most recent eval loss on record is the minimum of all recorded ones
             should_save = step % args.save_steps == 0 and len(eval_history) > 0 and eval_history[-1] == min(eval_history)
