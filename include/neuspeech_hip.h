@@ -270,6 +270,10 @@ typedef struct {
   int32_t groups, nq, H, Lk, Lk_max, head_dim;
   int32_t ldq, ldk, ldv, ldo, anc_ld;
   int64_t kv_group_stride, kv_pos_stride;
+  /* optional append (anc layout, nq == 1): Knew / Vnew = this step's key / value rows (row r at r*ldnew, head h at
+   * h*64) -- position Lk-1 is read from them and also written into the cache row (Lk-1)*kv_pos_stride + r, so the
+   * decode loop needs no separate cache-update launch (utils/load_model.py:1332-1351 keeps past_key_values). */
+  const void *Knew, *Vnew; int32_t ldnew, reserved;
 } ns_attn_decode_desc;
 int ns_attn_decode(const ns_attn_decode_desc* d, void* stream);
 

@@ -45,15 +45,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
   auto krow = [&](int j) -> long long {
     return anc ? (long long)j * p.kv_pos_stride + anc[j] : (long long)grp * p.kv_group_stride + j;
   };
+  // append mode: the newest position comes from this step's projection rows and is stored into the cache on the way
+  const half_t* const Kn = p.Knew ? (const half_t*)p.Knew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
+  const half_t* const Vn = p.Knew ? (const half_t*)p.Vnew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
+  if (Kn && sg == 0) {
+    const long long r = (long long)(Lk - 1) * p.kv_pos_stride + grp;
+    *(half8*)((half_t*)p.K + h * D + l8 * 8 + r * p.ldk) = *(const half8*)Kn;
+    *(half8*)((half_t*)p.V + h * D + l8 * 8 + r * p.ldv) = *(const half8*)Vn;
+  }
   // KU keys per subgroup and iteration: 2 KU independent 16-B loads in flight per lane
   constexpr int KU = 4;
   for (int j0 = sg * KU; j0 < Lk; j0 += 32 * KU) {
     half8 kv[KU], vv[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const long long r = krow(min(j0 + u, Lk - 1));
-      kv[u] = *(const half8*)(Kb + r * p.ldk);
-      vv[u] = *(const half8*)(Vb + r * p.ldv);
+      const int j = min(j0 + u, Lk - 1);
+      if (Kn && j == Lk - 1) {
+        kv[u] = *(const half8*)Kn;
+        vv[u] = *(const half8*)Vn;
+      } else {
+        const long long r = krow(j);
+        kv[u] = *(const half8*)(Kb + r * p.ldk);
+        vv[u] = *(const half8*)(Vb + r * p.ldv);
+      }
     }
     float s[NQ][KU];
 #pragma unroll
@@ -766,6 +780,7 @@ extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
   NS_CHECK_ARG(d->nq >= 1 && d->nq <= MAXQ && d->groups > 0 && d->H > 0 && d->Lk > 0 && d->Lk_max >= d->Lk,
                "ns_attn_decode: bad shape nq=%d groups=%d Lk=%d Lk_max=%d", d->nq, d->groups, d->Lk, d->Lk_max);
   NS_CHECK_ARG(!d->anc || d->nq == 1, "ns_attn_decode: ancestry indirection needs nq == 1");
+  NS_CHECK_ARG(!d->Knew || (d->Vnew && d->anc && d->nq == 1 && d->ldnew % 8 == 0), "ns_attn_decode: append needs Vnew, the ancestry layout, nq == 1 and ldnew % 8 == 0");
   NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0, "ns_attn_decode: strides must be multiples of 8");
   dim3 grid(d->groups, d->H);
   hipStream_t st = (hipStream_t)stream;

@@ -127,9 +127,9 @@ class Generator:
         fused_select = Vp <= ops.SELECT_MAX_LDV and not sb
         scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
 
-        def step(tok: torch.Tensor, t: int, parent, ctr=None, idx64=None):
+        def step(tok: torch.Tensor, t: int, parent, ctr=None):
             """Feed token `tok` (Bp,) at position t; leaves last-position logits in `logits`.
-            With `ctr` (device int32 [t, t+1]) / `idx64` (device int64 [t]) the position is read on the device."""
+            With `ctr` (device int32 [t, t+1]) the position is read on the device."""
             c0 = ctr
             c1 = (ctr, 1) if ctr is not None else None
             ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t, cur_dev=c0)
@@ -139,13 +139,10 @@ class Generator:
             for li, Lw in enumerate(eng.dec):
                 ops.layernorm_fwd(h[0], *Lw["ln1"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["qkv"], C16=qkv)
-                if idx64 is None:
-                    kvc[li].view(max_len, Bp, 2 * d)[t].copy_(qkv[:, d:])
-                else:
-                    kvc[li].view(max_len, Bp, 2 * d).index_copy_(0, idx64, qkv[:, d:].unsqueeze(0))
+                # the kernel reads position t from this step's k | v rows and appends them to the cache itself
                 ops.attn_decode(Q=qkv, K=kvc[li], V=(kvc[li], d), O=ao, groups=Bp, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
                                 ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a, anc_ld=max_len, kv_pos_stride=Bp,
-                                kv_len_dev=c1)
+                                kv_len_dev=c1, Knew=(qkv, d), Vnew=(qkv, 2 * d), ldnew=3 * d)
                 eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
                 ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
                 eng._lin(x16, Bp, Lw["cq"], C16=qc)
@@ -191,7 +188,7 @@ class Generator:
             feeds it at position `cur`.  First iteration eager (lazy kernel attributes / workspaces), then graphs."""
             nonlocal cur
             n_sel = 0
-            ctr = idx64 = None
+            ctr = None
             graphs = None
             while cur < max_len:
                 if graphs is None:
@@ -211,7 +208,6 @@ class Generator:
                     if graph_ok and max_len - cur >= self.graph_min_steps:
                         # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
                         ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
-                        idx64 = torch.tensor([cur], device=dev, dtype=torch.int64)
                         graphs = []
                         torch.cuda.synchronize()
                         for _ in range(2):
@@ -219,9 +215,8 @@ class Generator:
                             with torch.cuda.graph(gs):
                                 select(cur, ctr)
                             with torch.cuda.graph(gt):
-                                step(next_tok, cur, parent, ctr, idx64)
+                                step(next_tok, cur, parent, ctr)
                                 ctr.add_(1)
-                                idx64.add_(1)
                             graphs.append((gs, gt))
                 else:
                     graphs[(n_sel - 2) & 1][1].replay()

@@ -466,6 +466,23 @@ def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk):
     k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
     ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).reshape(rows, H * d)
     close(O, ref, 2e-3, 2e-3, "attn_decode anc")
+    # append mode: the newest position comes from the projection rows (k | v inside Q's rows) and lands in the cache
+    anc2 = anc.clone()
+    anc2[:, Lk - 1] = torch.arange(rows, device=dev, dtype=torch.int32)       # a row's newest position is its own slot
+    cache2 = cache.clone()
+    cache2.view(Lmax, rows, 2 * H * d)[Lk - 1] = 777.0                         # stale: must not be read, must be replaced
+    O2 = torch.full_like(O, float("nan"))
+    ops.attn_decode(Q=Q, K=cache2, V=(cache2, H * d), O=O2, groups=rows, nq=1, H=H, Lk=Lmax, Lk_max=Lmax, ldq=3 * H * d,
+                    ldk=2 * H * d, ldv=2 * H * d, ldo=H * d, anc=anc2, anc_ld=Lmax, kv_pos_stride=rows, kv_len_dev=klen,
+                    Knew=(Q, H * d), Vnew=(Q, 2 * H * d), ldnew=3 * H * d)
+    want = cache.clone()
+    want.view(Lmax, rows, 2 * H * d)[Lk - 1] = Q[:, H * d:]
+    assert torch.equal(cache2, want)
+    c = want.float().view(Lmax, rows, 2, H, d)
+    kv = c[torch.arange(Lk, device=dev).unsqueeze(0), anc2[:, :Lk].long()]
+    k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+    ref2 = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).reshape(rows, H * d)
+    close(O2, ref2, 2e-3, 2e-3, "attn_decode append")
 
 
 @pytest.mark.parametrize("nq,Lk", [(5, 1500), (1, 1500), (16, 97), (3, 31), (8, 128), (2, 1)])
