@@ -1,5 +1,6 @@
-"""__graft_entry__.smoke(): one tiny forward+backward+optimizer step of the hot path on cuda:0 through the
-HIP library, checked against the CPU oracle (the oracle is the checker only, never the product path)."""
+"""__graft_entry__.smoke(): one tiny forward+backward+optimizer step and one short greedy / beam decode of the hot path
+on cuda:0 through the HIP library, checked against the CPU oracle (the oracle is the checker only, never the product
+path)."""
 import torch
 
 
@@ -26,3 +27,17 @@ def run_smoke():
     assert abs(l0 - ref.item()) < 2e-3 * max(1.0, ref.item()), (l0, ref.item())
     assert eng.found_inf_dev.item() == 0 and l1 < l0, (l0, l1)
     print(f"[smoke] tiny train step ok: loss {l0:.4f} (oracle {ref.item():.4f}) -> {l1:.4f}")
+    # decode: token ids of the greedy and the beam-search loop against the oracle's (frozen weights, no adapters)
+    from .generate import Generator
+    gen = Generator(MegWhisperEngine(dims, sd, device=dev))
+    prompt = torch.from_numpy(labels[:, :4].copy())
+    kw = dict(repetition_penalty=5.0, no_repeat_ngram_size=2)
+    sdt = O.to_torch(sd)
+    got = gen.generate(xd, prompt.to(dev), num_beams=1, max_new_tokens=8, check_every=1, **kw).cpu()
+    want = O.greedy(sdt, torch.from_numpy(x), dims, prompt, 8, **kw)
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+    got = gen.generate(xd, prompt.to(dev), num_beams=3, max_new_tokens=6, check_every=1, **kw).cpu()
+    want = O.beam_search(sdt, torch.from_numpy(x), dims, prompt, 3, 6, **kw)
+    want = want[0] if isinstance(want, tuple) else want
+    assert torch.equal(got[:, :want.shape[1]], want), (got.tolist(), want.tolist())
+    print(f"[smoke] tiny greedy / beam-3 decode ok: ids {got[0, 4:].tolist()}")
