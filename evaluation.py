@@ -125,6 +125,7 @@ def main(argv=None):
         print(f"sequence bias: {len(sequence_bias)} token sequences")
     preds, refs = [], []
     n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
+    t_gen = 0.0
     with open(os.path.join(out_dir, base + ".txt"), "w") as f, torch.no_grad():
         for x, labels in batches():
             if args.noise:
@@ -137,8 +138,10 @@ def main(argv=None):
                     kw["max_new_tokens"] = args.max_new_tokens
                 if sequence_bias is not None:
                     kw["sequence_bias"] = sequence_bias
+                tg = time.time()
                 gen = model.generate(x, do_sample=False, num_beams=args.num_beams, repetition_penalty=5.0,
                                      no_repeat_ngram_size=2, **kw).cpu().numpy()
+                t_gen += time.time() - tg
                 n_new += int(gen.shape[0] * (gen.shape[1] - (4 if kw.get("decoder_input_ids") is not None else 1)))
             else:
                 ign = labels == -100
@@ -161,7 +164,8 @@ def main(argv=None):
                 f.write("end==================================\n\n")
     dt = time.time() - t0
     write_jsonlines(os.path.join(out_dir, base + ".jsonl"), [{"pred": p, "label": l} for p, l in zip(preds, refs)])
-    results = {"samples": len(preds), "seconds": round(dt, 3), "generated_tokens_per_s": round(n_new / dt, 2) if n_new else None,
+    results = {"samples": len(preds), "seconds": round(dt, 3), "generate_seconds": round(t_gen, 3),
+               "generated_tokens_per_s": round(n_new / dt, 2) if n_new else None,
                "teacher_forced_token_accuracy": round(n_match / n_lab, 5) if n_lab else None}
     print(f"results: {results}")
     with open(os.path.join(out_dir, base + ".json"), "w") as f:

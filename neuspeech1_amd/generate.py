@@ -212,9 +212,11 @@ class Generator:
                         torch.cuda.synchronize()
                         for _ in range(2):
                             gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(gs):
+                            # thread-local capture mode: other host threads (the data feed's loader thread issues copies
+                            # and a kernel on its own stream) must not invalidate this capture
+                            with torch.cuda.graph(gs, capture_error_mode="thread_local"):
                                 select(cur, ctr)
-                            with torch.cuda.graph(gt):
+                            with torch.cuda.graph(gt, capture_error_mode="thread_local"):
                                 step(next_tok, cur, parent, ctr)
                                 ctr.add_(1)
                             graphs.append((gs, gt))
