@@ -304,3 +304,25 @@ def test_finetune_with_default_timestamp_labels_at_whisper_base_dims(dev, tmp_pa
                    "--augment_config_path=configs/augmentation1.json", "--max_steps=3"])
     logs = [json.loads(l) for l in open(os.path.join(out, "synthetic_base", "train_log.jsonl"))]
     assert len(logs) == 3 and all(np.isfinite(l["loss"]) for l in logs) and logs[-1]["loss"] < logs[0]["loss"] + 0.5, logs
+
+
+def test_evaluation_graph_replay_with_the_feed_thread_running(dev, tmp_path):
+    """Long enough generations use hipGraph replay (Generator.graph_min_steps); the on-GPU feed stages the NEXT batch
+    from its loader thread while a capture is in progress (thread-local capture mode).  Same hypotheses as the host
+    reader path without graphs in the way."""
+    import evaluation
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 20, ch_file=24, name="toyset", seed=9, min_len=120, max_len=520)
+    common = [f"--test_data={jl}", "--model_path=synthetic:tiny", "--modal=eeg", "--eeg_ch=20", "--sampling_rate=200",
+              "--timestamps=False", "--max_audio_len=2.0", "--language=Dutch", "--num_workers=2", "--batch_size=4",
+              "--max_new_tokens=40"]
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        evaluation.main(common + ["--extra_name=feed"])
+        a = open("formal_test_results_feedno_post_processing.jsonl").read()
+        evaluation.main(common + ["--device_feed=False", "--extra_name=host"])
+        b = open("formal_test_results_hostno_post_processing.jsonl").read()
+    finally:
+        os.chdir(cwd)
+    assert len(a.splitlines()) == 20 and a == b
