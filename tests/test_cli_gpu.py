@@ -326,3 +326,29 @@ def test_evaluation_graph_replay_with_the_feed_thread_running(dev, tmp_path):
     finally:
         os.chdir(cwd)
     assert len(a.splitlines()) == 20 and a == b
+
+
+def test_transfer_recipe_merges_a_trained_adapter_then_trains_a_new_front_end(dev, tmp_path):
+    """The reference's pretrain -> transfer recipe (README.md:67-125; finetune.py:143-163): --lora_model merges an adapter
+    trained with --lora_eeg_ch input channels into the base weights, the front-end is replaced by a fresh one for
+    --eeg_ch channels, and new adapters are trained on top; --data_ratio keeps a prefix of the list."""
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    base = ["--base_model=synthetic:tiny", "--modal=eeg", "--sampling_rate=200", "--orig_sample_rate=200", "--timestamps=False",
+            "--max_audio_len=2.0", "--language=Dutch", "--num_workers=0", "--use_adalora=False", "--fp16=True",
+            "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1", "--eval_steps=100",
+            "--save_steps=100", "--warmup_steps=0", "--learning_rate=1e-3", "--augment_config_path=None"]
+    jl_a = write_synthetic_dataset(str(tmp_path / "a"), 8, ch_file=24, name="toyset", seed=11, min_len=120, max_len=400)
+    out_a = str(tmp_path / "out_a")
+    finetune.main([f"--train_data={jl_a}", f"--test_data={jl_a}", f"--output_dir={out_a}", "--eeg_ch=20", "--num_train_epochs=2"] + base)
+    ck = os.path.join(out_a, "synthetic_tiny", "checkpoint-final")
+    jl_b = write_synthetic_dataset(str(tmp_path / "b"), 16, ch_file=16, name="otherset", seed=12, min_len=120, max_len=400)
+    out_b = str(tmp_path / "out_b")
+    finetune.main([f"--train_data={jl_b}", f"--test_data={jl_b}", f"--output_dir={out_b}", "--eeg_ch=16", f"--lora_model={ck}",
+                   "--lora_eeg_ch=20", "--num_train_epochs=2", "--data_ratio=0.5"] + base)
+    logs = [json.loads(l) for l in open(os.path.join(out_b, "synthetic_tiny", "train_log.jsonl"))]
+    assert len(logs) == 4 and all(np.isfinite(l["loss"]) for l in logs), logs      # 8 of 16 samples, bs 4, 2 epochs
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(out_b, "synthetic_tiny", "checkpoint-final", "adapter_model.safetensors"))
+    assert sd["base_model.model.model.encoder.conv1.0.weight"].shape == (256, 16, 3)
+    assert sd["base_model.model.model.encoder.layers.0.fc1.lora_B.weight"].abs().sum() > 0
