@@ -158,6 +158,9 @@ def main(argv=None):
             dl = processor.batch_decode(lab, skip_special_tokens=True)
             preds.extend(dp)
             refs.extend(dl)
+            if args.post_processing:    # reference :417-421: the .txt listing shows the filtered text, the .jsonl keeps the raw one
+                from utils.process_str import convert_lower_text, filter_ascii_text
+                dp, dl = convert_lower_text(filter_ascii_text(dp)), convert_lower_text(filter_ascii_text(dl))
             for p, l in zip(dp, dl):
                 f.write("start********************************\n")
                 f.write(f"Predicted: {p}\nTrue: {l}\n")
