@@ -53,8 +53,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
     *(half8*)((half_t*)p.K + h * D + l8 * 8 + r * p.ldk) = *(const half8*)Kn;
     *(half8*)((half_t*)p.V + h * D + l8 * 8 + r * p.ldv) = *(const half8*)Vn;
   }
-  // KU keys per subgroup and iteration: 2 KU independent 16-B loads in flight per lane
-  constexpr int KU = 4;
+  // KU keys per subgroup and iteration (2 KU independent 16-B loads in flight per lane).  With K and V in the same pass
+  // and 8 workgroups per CU one key is enough: KU = 1 / 2 / 4 / 8 gave 101.0 / 100.2 / 99.4 / 98.6 k tokens/s greedy
+  // and 77.5 / 77.5 / 75.3 / 71.1 k beam-5 in a same-box sweep (short self-attention rows waste the wider forms)
+#ifndef NS_AD_KU
+#define NS_AD_KU 1
+#endif
+  constexpr int KU = NS_AD_KU;
   for (int j0 = sg * KU; j0 < Lk; j0 += 32 * KU) {
     half8 kv[KU], vv[KU];
 #pragma unroll
