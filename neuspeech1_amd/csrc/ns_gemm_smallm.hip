@@ -17,7 +17,13 @@
 
 namespace {
 
-constexpr int SM_NT = 256, SM_DEPTH = 3;   // loads of 3 K-steps in flight ahead of the one being multiplied
+#ifndef NS_SM_DEPTH
+#define NS_SM_DEPTH 3      // 1 or 3 (ring of DEPTH + 1 stages, power of two)
+#endif
+#ifndef NS_SM_MAXTILES
+#define NS_SM_MAXTILES 384
+#endif
+constexpr int SM_NT = 256, SM_DEPTH = NS_SM_DEPTH;   // loads of SM_DEPTH K-steps in flight ahead of the one being multiplied
 typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
 
 struct sm_frags {
@@ -110,7 +116,7 @@ bool ns_gemm_smallm_ok(const ns_gemm_desc* d) {
   if ((d->flags & NS_GEMM_TN) || d->K2 != 0 || d->drop_p != 0.f || d->am.seg_rows != 0 || d->M > 1024 || d->N < 64 ||
       d->N > 4096 || d->K < 256)
     return false;
-  return ((d->M + 31) / 32) * ((d->N + 31) / 32) <= 384;
+  return ((d->M + 31) / 32) * ((d->N + 31) / 32) <= NS_SM_MAXTILES;
 }
 
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st) {
