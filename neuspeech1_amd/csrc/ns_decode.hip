@@ -162,8 +162,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
 typedef float fq_f32x4 __attribute__((ext_vector_type(4)));
 struct fq_frags { half8 k[2][2]; half8 v[4]; };   // k[tile][k32 half], v[dim tile]
 
-__global__ __launch_bounds__(256) void attn_fewq_kernel(const ns_attn_fewq_desc p) {
-  __shared__ float red[4][16][D + 2];
+#ifndef NS_FQ_WAVES
+#define NS_FQ_WAVES 4
+#endif
+constexpr int FQ_W = NS_FQ_WAVES;   // waves per workgroup = ways the keys are split
+__global__ __launch_bounds__(64 * FQ_W) void attn_fewq_kernel(const ns_attn_fewq_desc p) {
+  __shared__ float red[FQ_W][16][D + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x, h = blockIdx.y, Lk = p.Lk;
   half8 zero8;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const ns_attn_fewq_desc 
   const half_t* Kg = (const half_t*)p.K + (long long)grp * Lk * p.ldk + h * D + 8 * lg;
   const half_t* Vg = (const half_t*)p.Vt + ((long long)(grp * p.H + h) * D + lr) * p.ldvt + 8 * lg;
   const int krow0 = 8 * (lr >> 2) + (lr & 3);
-  const int chunk = (((Lk + 3) >> 2) + 31) & ~31;
+  const int chunk = (((Lk + FQ_W - 1) / FQ_W) + 31) & ~31;
   const int k_begin = wave * chunk, k_end = min(Lk, k_begin + chunk);
 
   auto load = [&](int k0, fq_frags& f) __attribute__((always_inline)) {
@@ -256,14 +260,14 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const ns_attn_fewq_desc 
     for (int i = 0; i < 4; ++i) red[wave][lr][16 * dt + 4 * lg + i] = o[dt][i];
   if (lg == 0) { red[wave][lr][D] = m; red[wave][lr][D + 1] = l; }
   __syncthreads();
-  for (int idx = tid; idx < p.nq * D; idx += 256) {
+  for (int idx = tid; idx < p.nq * D; idx += 64 * FQ_W) {
     const int qi = idx >> 6, dd = idx & 63;
     float M = red[0][qi][D];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) M = fmaxf(M, red[w][qi][D]);
+    for (int w = 1; w < FQ_W; ++w) M = fmaxf(M, red[w][qi][D]);
     float v = 0.f, L = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < FQ_W; ++w) {
       const float mw = red[w][qi][D];
       const float sc = mw == -INFINITY ? 0.f : __expf(mw - M);
       v += red[w][qi][dd] * sc;
@@ -807,7 +811,7 @@ extern "C" int ns_attn_fewq(const ns_attn_fewq_desc* d, void* stream) {
                d->nq, d->groups, d->Lk);
   NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 32 == 0 && d->ldvt >= d->Lk,
                "ns_attn_fewq: ldq / ldk must be multiples of 8, ldvt a multiple of 32 and >= Lk");
-  hipLaunchKernelGGL(attn_fewq_kernel, dim3(d->groups, d->H), dim3(256), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(attn_fewq_kernel, dim3(d->groups, d->H), dim3(64 * FQ_W), 0, (hipStream_t)stream, *d);
   NS_CHECK_LAUNCH("ns_attn_fewq");
   return NS_OK;
 }
