@@ -64,8 +64,6 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print_arguments(args)
-    if args.random_choice:
-        raise NotImplementedError("--random_choice (labels shuffled as predictions, no model involved) is outside the hot path")
     assert args.model_path.startswith("synthetic:") or os.path.exists(args.model_path), f"model {args.model_path} not found"
     from finetune import get_processor
     processor = get_processor(args.model_path, args.language, args.task, args.timestamps, args.local_files_only)
@@ -95,7 +93,22 @@ def main(argv=None):
                                          collate_fn=collator)
     base = (f'formal_test_results{"_" + args.extra_name if args.extra_name is not None else ""}'
             f'{"no_post_processing" if not args.post_processing else "post_processing"}'
-            f'{"_noise" if args.noise else ""}{"_tf" if args.teacher_forcing else ""}')
+            f'{"_noise" if args.noise else ""}{"_randomChoice" if args.random_choice else ""}'
+            f'{"_tf" if args.teacher_forcing else ""}')
+    if args.random_choice:
+        # chance baseline of the reference (:330-331, :406-420, :462-466): every prediction is a label drawn at random
+        # from the test list itself; the model is not run
+        all_labels = []
+        for batch in loader:
+            lab = np.where(batch["labels"].numpy() != -100, batch["labels"].numpy(), processor.tokenizer.pad_token_id)
+            all_labels.extend(processor.batch_decode(lab, skip_special_tokens=True))
+        all_preds = np.random.choice(all_labels, len(all_labels)).tolist()
+        write_jsonlines(os.path.join(out_dir, base + ".jsonl"), [{"pred": p, "label": l} for p, l in zip(all_preds, all_labels)])
+        results = {"samples": len(all_labels), "random_choice": True}
+        print(f"results: {results}")
+        with open(os.path.join(out_dir, base + ".json"), "w") as f:
+            json.dump(results, f)
+        return
     feed = None
     if args.device_feed and not args.noise and model.device.type == "cuda":
         # recordings go to the GPU as bytes; slice / pad / crop / cast run there (neuspeech1_amd/feed.py)

@@ -281,6 +281,10 @@ def test_evaluation_with_sequence_bias(dev, tmp_path, capsys):
         biased = open("formal_test_results_sbno_post_processing.jsonl").read()
         with pytest.raises(ImportError):
             evaluation.main(common + ["--add_sequence_bias=True"])
+        # --random_choice: the reference's chance baseline (labels drawn at random as predictions, model not run)
+        evaluation.main(common + ["--random_choice=True"])
+        rc = [json.loads(l) for l in open("formal_test_resultsno_post_processing_randomChoice.jsonl")]
+        assert len(rc) == 8 and {r["pred"] for r in rc} <= {r["label"] for r in rc}
     finally:
         os.chdir(cwd)
     assert len(biased.splitlines()) == 8 and len(plain.splitlines()) == 8
