@@ -82,6 +82,9 @@ def main(argv=None):
     if args.lora_model is not None:
         model = PeftModel.from_pretrained(model, args.lora_model, local_files_only=args.local_files_only)
         model = model.merge_and_unload()
+    if args.random_initialize_whisper:
+        model.model.decoder.post_init()     # reference :90-91: the decoder only
+        model._engine = None
     model.eval()
     test_dataset = CustomDataset(data_list_path=args.test_data, processor=processor, timestamps=args.timestamps,
                                  modal=args.modal, mode="test", modal_ch=args.eeg_ch, filter_dataset=args.filter_dataset,

@@ -264,6 +264,9 @@ def main(argv=None):
         if args.lora_eeg_ch != args.eeg_ch:
             conv1 = projection_module(config_name=args.config_name, meg_ch=args.eeg_ch, d_model=d_model).to(model.device)
             model.model.encoder.set_input_embeddings(conv1)
+    if args.random_initialize_whisper:
+        model.post_init()       # reference :166-168
+        print("model re-initialised at random")
     model.config.forced_decoder_ids = None
     model.config.suppress_tokens = []
     model = prepare_model_for_kbit_training(model)

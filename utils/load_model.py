@@ -97,11 +97,45 @@ class WhisperEncoder(nn.Module):
 class WhisperDecoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
+        self._init_std = getattr(cfg, "init_std", 0.02)
         d = cfg.d_model
         self.embed_tokens = nn.Embedding(cfg.vocab_size, d)
         self.embed_positions = nn.Embedding(cfg.max_target_positions, d)
         self.layers = nn.ModuleList([WhisperDecoderLayer(d, cfg.decoder_ffn_dim) for _ in range(cfg.decoder_layers)])
         self.layer_norm = nn.LayerNorm(d)
+
+    def post_init(self):
+        _hf_init_weights(self, self._init_std)
+
+
+def _sinusoids(length, channels, max_timescale=10000.0):
+    """HF:modeling_whisper.py sinusoids(): the encoder's fixed position table"""
+    import math
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length).view(-1, 1) * inv.view(1, -1)
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+@torch.no_grad()
+def _hf_init_weights(root: nn.Module, std: float):
+    """transformers PreTrainedModel.post_init() -> init_weights(): what --random_initialize_whisper triggers in the
+    reference (finetune.py:166-168 on the whole model, evaluation.py:90-91 on the decoder).  Linear / Conv1d / Embedding
+    weights ~ N(0, init_std), biases 0, LayerNorm (1, 0), the encoder's position table back to its sinusoids."""
+    for m in root.modules():
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            m.weight.normal_(0.0, std)
+            if m.bias is not None:
+                m.bias.zero_()
+        elif isinstance(m, nn.Embedding):
+            m.weight.normal_(0.0, std)
+        elif isinstance(m, nn.LayerNorm):
+            m.weight.fill_(1.0)
+            m.bias.zero_()
+    for m in root.modules():
+        if isinstance(m, WhisperEncoder):
+            w = m.embed_positions.weight
+            w.copy_(_sinusoids(*w.shape).to(w))
 
 
 class WhisperModel(nn.Module):
@@ -214,6 +248,11 @@ class WhisperForConditionalGeneration(nn.Module):
 
     def invalidate_engine(self):
         """call after editing frozen weights in place"""
+        self._engine = None
+
+    def post_init(self):
+        """random re-initialisation of every weight (what --random_initialize_whisper does through HF's post_init)"""
+        _hf_init_weights(self, getattr(self.config, "init_std", 0.02))
         self._engine = None
 
     # ------------------------------------------------------------------ engine
