@@ -67,7 +67,21 @@ def main(argv=None):
     assert args.model_path.startswith("synthetic:") or os.path.exists(args.model_path), f"model {args.model_path} not found"
     from finetune import get_processor
     processor = get_processor(args.model_path, args.language, args.task, args.timestamps, args.local_files_only)
-    model = WhisperForConditionalGeneration.from_pretrained(args.model_path, device_map="auto",
+    # one process per GPU under torchrun: every rank is a full replica decoding a strided shard of the test list; the only
+    # exchange is the gather of the decoded TEXT at the end ("replicas only").  Single process otherwise,
+    # exactly the reference's flow.
+    world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK") or 0)
+    device_map = "auto"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            local %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+        device_map = {"": local}
+        dist.init_process_group("gloo")         # text gather only: no GPU collective on the decode path
+    model = WhisperForConditionalGeneration.from_pretrained(args.model_path, device_map=device_map,
                                                             local_files_only=args.local_files_only)
     torch.manual_seed(42)
     loaded = model.model.encoder.conv1
@@ -92,13 +106,14 @@ def main(argv=None):
                                  min_duration=args.min_audio_len, max_duration=args.max_audio_len)
     print(f"test samples: {len(test_dataset)}")
     collator = DataCollatorSpeechSeq2SeqWithPadding(processor=processor)
-    loader = torch.utils.data.DataLoader(test_dataset, batch_size=args.batch_size, num_workers=args.num_workers,
-                                         collate_fn=collator)
+    shard = test_dataset if world == 1 else torch.utils.data.Subset(test_dataset, list(range(rank, len(test_dataset), world)))
+    loader = torch.utils.data.DataLoader(shard, batch_size=args.batch_size, num_workers=args.num_workers, collate_fn=collator)
     base = (f'formal_test_results{"_" + args.extra_name if args.extra_name is not None else ""}'
             f'{"no_post_processing" if not args.post_processing else "post_processing"}'
             f'{"_noise" if args.noise else ""}{"_randomChoice" if args.random_choice else ""}'
             f'{"_tf" if args.teacher_forcing else ""}')
     if args.random_choice:
+        assert world == 1, "--random_choice is a single-process baseline"
         # chance baseline of the reference (:330-331, :406-420, :462-466): every prediction is a label drawn at random
         # from the test list itself; the model is not run
         all_labels = []
@@ -142,7 +157,8 @@ def main(argv=None):
     preds, refs = [], []
     n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
     t_gen = 0.0
-    with open(os.path.join(out_dir, base + ".txt"), "w") as f, torch.no_grad():
+    txt_path = os.path.join(out_dir, base + ".txt") if world == 1 else os.devnull   # ranks > 1: rank 0 writes it after the gather
+    with open(txt_path, "w") as f, torch.no_grad():
         for x, labels in batches():
             if args.noise:
                 x = torch.randn_like(x)
@@ -182,8 +198,29 @@ def main(argv=None):
                 f.write(f"Predicted: {p}\nTrue: {l}\n")
                 f.write("end==================================\n\n")
     dt = time.time() - t0
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (preds, refs, n_new, n_match, n_lab, dt, t_gen))
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        n = sum(len(p[0]) for p in parts)
+        preds = [parts[i % world][0][i // world] for i in range(n)]     # undo the strided shard: original list order
+        refs = [parts[i % world][1][i // world] for i in range(n)]
+        n_new, n_match, n_lab = (sum(p[k] for p in parts) for k in (2, 3, 4))
+        dt, t_gen = max(p[5] for p in parts), max(p[6] for p in parts)
+        with open(os.path.join(out_dir, base + ".txt"), "w") as f:
+            dp, dl = preds, refs
+            if args.post_processing:
+                from utils.process_str import convert_lower_text, filter_ascii_text
+                dp, dl = convert_lower_text(filter_ascii_text(dp)), convert_lower_text(filter_ascii_text(dl))
+            for p, l in zip(dp, dl):
+                f.write("start********************************\n")
+                f.write(f"Predicted: {p}\nTrue: {l}\n")
+                f.write("end==================================\n\n")
     write_jsonlines(os.path.join(out_dir, base + ".jsonl"), [{"pred": p, "label": l} for p, l in zip(preds, refs)])
-    results = {"samples": len(preds), "seconds": round(dt, 3), "generate_seconds": round(t_gen, 3),
+    results = {"samples": len(preds), "n_gpus": world, "seconds": round(dt, 3), "generate_seconds": round(t_gen, 3),
                "generated_tokens_per_s": round(n_new / dt, 2) if n_new else None,
                "teacher_forced_token_accuracy": round(n_match / n_lab, 5) if n_lab else None}
     print(f"results: {results}")

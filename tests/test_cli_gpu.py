@@ -356,3 +356,43 @@ def test_transfer_recipe_merges_a_trained_adapter_then_trains_a_new_front_end(de
     sd = load_file(os.path.join(out_b, "synthetic_tiny", "checkpoint-final", "adapter_model.safetensors"))
     assert sd["base_model.model.model.encoder.conv1.0.weight"].shape == (256, 16, 3)
     assert sd["base_model.model.model.encoder.layers.0.fc1.lora_B.weight"].abs().sum() > 0
+
+
+def test_evaluation_sharded_over_two_ranks_matches_single_process(dev, tmp_path):
+    """Decode scales by replicas: under torchrun every rank decodes a strided shard of the test list and
+    rank 0 writes the merged outputs in the original order.  Two ranks (both on this box's one GPU; the gather is
+    text over gloo) against the single-process run."""
+    import socket
+    import subprocess
+    import sys
+    import evaluation
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 11, ch_file=24, name="toyset", seed=13, min_len=120, max_len=520)
+    common = [f"--test_data={jl}", "--model_path=synthetic:tiny", "--modal=eeg", "--eeg_ch=20", "--sampling_rate=200",
+              "--timestamps=False", "--max_audio_len=2.0", "--language=Dutch", "--num_workers=0", "--batch_size=3",
+              "--max_new_tokens=8"]
+    cwd = os.getcwd()
+    one, two = tmp_path / "one", tmp_path / "two"
+    os.makedirs(one), os.makedirs(two)
+    os.chdir(str(one))
+    try:
+        evaluation.main(common)
+    finally:
+        os.chdir(cwd)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "evaluation.py")] + common, cwd=str(two), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    name = "formal_test_resultsno_post_processing"
+    assert open(two / f"{name}.jsonl").read() == open(one / f"{name}.jsonl").read()
+    assert open(two / f"{name}.txt").read() == open(one / f"{name}.txt").read()
+    res = json.load(open(two / f"{name}.json"))
+    assert res["samples"] == 11 and res["n_gpus"] == 2
