@@ -111,11 +111,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("NS_DIST_BACKEND", "nccl") != "nccl":
+        local %= max(1, torch.cuda.device_count())      # test mode: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI; NS_DIST_BACKEND=gloo exists for the two-ranks-on-one-GPU test (RCCL refuses a shared device)
+        if os.environ.get("NS_DIST_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(os.environ["NS_DIST_BACKEND"])
 
     dims = WhisperDims(ch=args.ch)
     B = args.batch

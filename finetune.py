@@ -249,7 +249,12 @@ def main(argv=None):
         torch.cuda.set_device(local)
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL in production; NS_DIST_BACKEND=gloo lets two ranks share ONE GPU in the tests (RCCL refuses that)
+        backend = os.environ.get("NS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
     print(f"device map :{device_map}")
     model = WhisperForConditionalGeneration.from_pretrained(args.base_model, load_in_8bit=args.use_8bit,
                                                             device_map=device_map, local_files_only=args.local_files_only)
@@ -389,6 +394,8 @@ def main(argv=None):
         model.save_pretrained(os.path.join(output_dir, "checkpoint-final"))
         print(f"saved {os.path.join(output_dir, 'checkpoint-final')}")
     if ddp:
+        # replicas must have stayed identical: one line per rank for the logs (and for tests/test_cli_gpu.py)
+        print(f"[rank {rank}] trainable checksum {eng.P.double().sum().item():.9e} after {step} steps", flush=True)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

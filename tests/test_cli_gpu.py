@@ -396,3 +396,70 @@ def test_evaluation_sharded_over_two_ranks_matches_single_process(dev, tmp_path)
     assert open(two / f"{name}.txt").read() == open(one / f"{name}.txt").read()
     res = json.load(open(two / f"{name}.json"))
     assert res["samples"] == 11 and res["n_gpus"] == 2
+
+
+def test_finetune_two_ranks_data_parallel_on_one_gpu(dev, tmp_path):
+    """The data-parallel path end to end with two real processes (finetune.py:115-122 -> DDP in the reference): disjoint
+    DistributedSampler shards, gradient all-reduce(AVG) in chunks on the side stream, identical decisions on both ranks.
+    RCCL cannot put two ranks on this box's single GPU, so the collective runs over gloo (NS_DIST_BACKEND); everything
+    else is the production path.  Replicas must end bit-identical, and close to the single-process run over the same
+    global batches (not equal: DDP averages per-rank token means)."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    import finetune
+    from neuspeech1_amd.synthetic import write_synthetic_dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = write_synthetic_dataset(str(tmp_path / "data"), 16, ch_file=24, name="toyset", seed=21, min_len=200, max_len=400)
+    base = [f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", "--modal=eeg", "--eeg_ch=20",
+            "--sampling_rate=200", "--orig_sample_rate=200", "--timestamps=False", "--max_audio_len=2.0", "--language=Dutch",
+            "--num_workers=0", "--use_adalora=False", "--fp16=True", "--num_train_epochs=2", "--per_device_eval_batch_size=4",
+            "--logging_steps=1", "--eval_steps=4", "--save_steps=4", "--warmup_steps=0", "--learning_rate=1e-3",
+            "--augment_config_path=None"]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NS_DIST_BACKEND="gloo", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "finetune.py"), f"--output_dir={tmp_path / 'ddp'}",
+                                       "--per_device_train_batch_size=2"] + base, cwd=str(tmp_path), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    sums = [re.search(r"\[rank (\d)\] trainable checksum (\S+) after (\d+) steps", o) for o in outs]
+    assert all(sums) and sums[0].group(2) == sums[1].group(2) and sums[0].group(3) == "8", [m and m.groups() for m in sums]
+    ddp_logs = [json.loads(l) for l in open(tmp_path / "ddp" / "synthetic_tiny" / "train_log.jsonl")]
+    assert os.path.exists(tmp_path / "ddp" / "synthetic_tiny" / "checkpoint-final" / "adapter_model.safetensors")
+    # single process over the same global batches (bs 4 = 2 ranks x 2)
+    finetune.main([f"--output_dir={tmp_path / 'one'}", "--per_device_train_batch_size=4"] + base)
+    one_logs = [json.loads(l) for l in open(tmp_path / "one" / "synthetic_tiny" / "train_log.jsonl")]
+    assert len(ddp_logs) == len(one_logs) == 8
+    assert ddp_logs[-1]["loss"] < ddp_logs[0]["loss"]
+    # rank 0 logs ITS shard's loss, the single process the whole batch's: same trajectory, not the same numbers
+    assert abs(ddp_logs[-1]["loss"] - one_logs[-1]["loss"]) < 0.15 * one_logs[-1]["loss"], (ddp_logs, one_logs)
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
+    """bench.py under the driver's multi-GPU launch line (one rank per process, barrier + max-over-ranks timing, ONE JSON
+    line from rank 0, whole-job value): two ranks sharing this box's GPU over gloo, small batch."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, NS_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    assert d["roofline"]["kernel"] and d["cpu_baseline"] is None and d["vs_baseline"] is None
