@@ -382,6 +382,10 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
       NS_CHECK_ARG(d->K2 % 16 == 0 && d->am2.ld % 8 == 0 && d->ldb2 % 8 == 0,
                    "ns_gemm(NT): K2=%d must be a multiple of 16, lda2=%d/ldb2=%d multiples of 8", d->K2, d->am2.ld, d->ldb2);
       NS_CHECK_ARG(d->a2_ngroup == 0 || d->a2_ngroup % 128 == 0, "ns_gemm: a2_ngroup must be a multiple of 128");
+      // column group g of the output reads A2 columns [g*K2, (g+1)*K2): the row stride of A2 must hold every group
+      NS_CHECK_ARG(d->a2_ngroup == 0 || (long long)((d->N + d->a2_ngroup - 1) / d->a2_ngroup) * d->K2 <= d->am2.ld,
+                   "ns_gemm: A2 has %d columns per row but N=%d / a2_ngroup=%d needs %d groups of K2=%d", d->am2.ld, d->N,
+                   d->a2_ngroup, (d->N + d->a2_ngroup - 1) / d->a2_ngroup, d->K2);
     }
     NS_CHECK_ARG(!(d->flags & NS_GEMM_ATOMIC32), "ns_gemm(NT): ATOMIC32 is a TN-only epilogue");
   } else {

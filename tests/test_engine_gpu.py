@@ -399,3 +399,28 @@ def test_full_model_adapters_vs_oracle(dev, adalora):
     assert rel(lg.float().cpu(), o_logits) < 1e-2
     ls = [eng2.train_step(xd, ld).item() for _ in range(5)]
     assert ls[-1] < ls[0] and eng2.found_inf_dev.item() == 0, ls
+
+
+def test_base_shape_lora_forward_backward_vs_oracle(dev):
+    """LoRA r = 32 at the BASELINE dims (whisper-base, 208 channels, T = 6000; B = 1 so the CPU oracle stays in seconds):
+    the phase-interleaved / ring GEMM kernels and the full-size attention kernels, not the small-shape fallbacks, against
+    the oracle's loss and adapter gradients."""
+    from oracle import whisper_meg_oracle as O
+    dims = WHISPER_BASE
+    eng, sd, lora_sd = make_engine(dims, dev, 32)
+    x, labels = synth_batch(dims, 1, 31)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, 2.0)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss.item(), o_loss.item())
+    got = engine_grads(eng, dims, 32)
+    bad = {}
+    for k, ref in og.items():
+        if k in got and ("lora" in k or "bias" in k):
+            e = rel(got[k], ref)
+            if not e < 4e-2:
+                bad[k] = e
+    assert not bad, bad
+    assert len([k for k in og if "lora" in k]) == dims.enc_layers * 12

@@ -508,3 +508,71 @@ def test_attn_fewq_and_vt_pack(ops, dev, nq, Lk):
         ops.attn_decode(Q=Q, K=KV, V=(KV, H * d), O=O2, groups=groups, nq=nq, H=H, Lk=Lk, Lk_max=Lk, ldq=H * d,
                         ldk=2 * H * d, ldv=2 * H * d, ldo=H * d, kv_group_stride=Lk)
         close(O, O2.float(), 3e-3, 3e-3, "attn_fewq vs attn_decode")
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_wide_nt_kernels_agree_on_every_epilogue_and_ragged_shape(ops, dev, mode):
+    """The dispatch picks the 128^2 ring (2), the one-barrier 256^2 ring (3) or the phase-interleaved 256^2 kernel (4) by
+    size, so small parity cases never reach the big ones: force each on ragged shapes (M, N, K not multiples of the
+    tiles) with every epilogue and operand feature of the descriptor, against the register-staged kernel (mode 0) and
+    torch."""
+    from neuspeech1_amd import lib
+    M, N, K, S, r = 520, 760, 144, 130, 32
+    A, B = rnd((M, K), dev, seed=1), rnd((N, K), dev, 0.1, seed=2)
+    bias = rnd((N,), dev, 0.2, torch.float32, seed=3)
+    R = rnd((M, N), dev, 1.0, torch.float32, seed=4)
+    pos = rnd((S, N), dev, 1.0, torch.float32, seed=5)
+    P = rnd((M, N), dev, 1.0, seed=6)
+    u, Bs = rnd((M, 2 * r), dev, 0.5, seed=7), rnd((N, r), dev, 0.1, seed=8)
+    # conv-style operand: 4 segments of 132 output rows, stride-2 overlapping rows over a halo-padded token-major image
+    Cin, T2 = 48, 132
+    Rc = rnd((4 * T2, N), dev, 1.0, torch.float32, seed=11)
+    img = rnd((4, 2 * T2 + 2, Cin), dev, 1.0, seed=9)
+    Wc = rnd((N, 3 * Cin), dev, 0.1, seed=10)
+
+    def run():
+        out = {}
+        C16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16); G16 = torch.full_like(C16, float("nan"))
+        H = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=C16, c16m=ops.rowmap(N), G16=G16,
+                 g16m=ops.rowmap(N), R32=R, H32=H, h32m=ops.rowmap(N), pos=pos, pos_rows=S,
+                 flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD)
+        out["gelu_save"] = (C16, G16, H)
+        D = torch.full_like(C16, float("nan"))
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N),
+                 flags=ops.NS_GEMM_MUL_P16, alpha=0.5)
+        out["mul_p16"] = (D,)
+        D2 = torch.full_like(C16, float("nan"))
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D2, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N),
+                 flags=ops.NS_GEMM_DGELU)
+        out["dgelu"] = (D2,)
+        E = torch.full_like(C16, float("nan"))
+        # second product with two column groups of 384 (a2_ngroup must be a multiple of 128; the last group is ragged)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(2 * r), K2=r, B2=Bs, ldb2=r,
+                 a2_ngroup=384, bias=bias, C16=E, c16m=ops.rowmap(N))
+        out["second"] = (E,)
+        Hc = Rc.clone()
+        ops.gemm(A=(img, 0), am=ops.rowmap(2 * Cin, T2, (2 * T2 + 2) * Cin), K=3 * Cin, B=Wc, ldb=3 * Cin, M=4 * T2, N=N,
+                 bias=bias, R32=Hc, H32=Hc, h32m=ops.rowmap(N))
+        out["conv_res_inplace"] = (Hc,)
+        return out
+    try:
+        lib.load().ns_debug_set_ring(0)
+        ref = run()
+        lib.load().ns_debug_set_ring(mode)
+        got = run()
+    finally:
+        lib.load().ns_debug_set_ring(1)
+    for k in ref:
+        for a, b in zip(got[k], ref[k]):
+            assert not torch.isnan(a.float()).any(), k
+            close(a, b.float(), 4e-3, 3e-3, f"{k} (mode {mode} vs staged)")
+    # and the staged kernel itself against torch on the two least obvious ones
+    full = A.float() @ B.float().T
+    sec = full + bias
+    sec[:, :384] += u[:, :r].float() @ Bs[:384].float().T
+    sec[:, 384:] += u[:, r:].float() @ Bs[384:].float().T
+    close(ref["second"][0], sec, 6e-3, 3e-3, "second product groups")
+    conv = torch.nn.functional.conv1d(img.float().transpose(1, 2), Wc.float().view(N, 3, Cin).permute(0, 2, 1), stride=2)  # (4, N, T2)
+    close(ref["conv_res_inplace"][0], Rc + (conv.transpose(1, 2).reshape(4 * T2, N) + bias).half().float(),
+          2e-2, 3e-3, "conv rowmap")
