@@ -424,3 +424,33 @@ def test_base_shape_lora_forward_backward_vs_oracle(dev):
                 bad[k] = e
     assert not bad, bad
     assert len([k for k in og if "lora" in k]) == dims.enc_layers * 12
+
+
+def test_base_shape_step_is_the_same_through_the_big_gemm_kernels(dev):
+    """At the bench size the encoder GEMMs dispatch to the phase-interleaved 256^2 kernel (M >= 2048 and >= 192 tiles),
+    which the B = 1 / 2 oracle cases never reach: one LoRA step with dropout at whisper-base dims, B = 8, under the
+    automatic dispatch against the same step forced through the register-staged kernel (the one the oracle cases pin)."""
+    from neuspeech1_amd import lib
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    dims = WHISPER_BASE
+    sd = make_state_dict(dims, 42)
+    lora_sd = make_lora_state(dims, 32)
+    x, labels = synth_batch(dims, 8, 55)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.load().ns_debug_set_ring(mode)
+            eng = MegWhisperEngine(dims, sd, lora=LoraSpec(r=32, alpha=64.0, dropout=0.05), lora_sd=lora_sd,
+                                   train_cfg=TrainCfg(lr=1e-3), device=dev)
+            eng.drop_seed = 777
+            eng.zero_grad()
+            loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+            eng.backward()
+            res[mode] = (loss.item(), eng.G.clone(), eng._b["enc16"].float().clone())
+            del eng
+    finally:
+        lib.load().ns_debug_set_ring(1)
+    assert abs(res[0][0] - res[1][0]) < 1e-3 * max(1.0, abs(res[0][0])), (res[0][0], res[1][0])
+    assert rel(res[1][2], res[0][2]) < 2e-3
+    assert rel(res[1][1], res[0][1]) < 1e-2
