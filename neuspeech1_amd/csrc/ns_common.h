@@ -57,6 +57,29 @@ __device__ __forceinline__ void ns_gelu_both(float x, float& g, float& dg) {
   g = x * cdf;
   dg = cdf + x * pdf;
 }
+// Two elements at a time with packed fp32 arithmetic (v_pk_mul / v_pk_fma_f32: two lanes' worth of FMA per issue slot on
+// gfx950); exp and rcp stay scalar.  Same formula, same constants, same rounding per element as ns_gelu_both.
+typedef float ns_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ns_gelu_both2(ns_f2 x, ns_f2& g, ns_f2& dg) {
+  const ns_f2 ax = {fabsf(x.x), fabsf(x.y)};
+  const ns_f2 z = ax * 0.70710678118654752440f;
+  const ns_f2 den = z * 0.3275911f + 1.0f;
+  const ns_f2 t = {__frcp_rn(den.x), __frcp_rn(den.y)};
+  const ns_f2 nz2 = -z * z;
+  const ns_f2 e = {__expf(nz2.x), __expf(nz2.y)};
+  ns_f2 poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly = poly * t;
+  const ns_f2 erf_abs = 1.0f - poly * e;
+  const ns_f2 erf_s = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+  const ns_f2 cdf = erf_s * 0.5f + 0.5f;
+  const ns_f2 pdf = e * 0.39894228040143267794f;
+  g = x * cdf;
+  dg = x * pdf + cdf;
+}
+
 __device__ __forceinline__ float ns_gelu_grad(float x) {
   float cdf, pdf;
   ns_gelu_terms(x, cdf, pdf);

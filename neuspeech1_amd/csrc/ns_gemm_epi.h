@@ -161,11 +161,11 @@ __device__ __forceinline__ void ns_epi_finish(const ns_gemm_desc& p, const float
       half4 gv = v16, cv = v16;
       if (do_gelu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float g_, dg_;
-          ns_gelu_both((float)v16[e], g_, dg_);
-          gv[e] = (half_t)g_;
-          if (save_grad) cv[e] = (half_t)dg_;
+        for (int e = 0; e < 4; e += 2) {
+          ns_f2 g_, dg_;
+          ns_gelu_both2(ns_f2{(float)v16[e], (float)v16[e + 1]}, g_, dg_);
+          gv[e] = (half_t)g_.x; gv[e + 1] = (half_t)g_.y;
+          if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
         }
       }
       if (C16) *(half4*)(C16 + oc + col) = cv;

@@ -184,6 +184,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 #else
 #define NS_P8_MMA(AH, BH) mma(AH, BH)
 #endif
+#ifdef NS_P8_SETPRIO
+#define NS_P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define NS_P8_PRIO(x) do {} while (0)
+#endif
   // load part done -> barrier -> fragments landed -> MFMA cluster -> barrier
 #define NS_P8_RUN(AH, BH)                                   \
   do {                                                      \
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     NS_P8_BARRIER();                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);                      \
+    NS_P8_PRIO(1);                                          \
     NS_P8_MMA(AH, BH);                                      \
+    NS_P8_PRIO(0);                                          \
     __builtin_amdgcn_sched_barrier(0);                      \
     NS_P8_BARRIER();                                        \
   } while (0)
@@ -349,11 +356,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
         half8 gv = v, cv = v;
         if (do_gelu) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float g_, dg_;
-            ns_gelu_both((float)v[e], g_, dg_);
-            gv[e] = (half_t)g_;
-            if (save_grad) cv[e] = (half_t)dg_;
+          for (int e = 0; e < 8; e += 2) {
+            ns_f2 g_, dg_;
+            ns_gelu_both2(ns_f2{(float)v[e], (float)v[e + 1]}, g_, dg_);
+            gv[e] = (half_t)g_.x; gv[e + 1] = (half_t)g_.y;
+            if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
           }
         }
         if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = cv;
