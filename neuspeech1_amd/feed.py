@@ -243,7 +243,7 @@ class SignalFeed:
         torch.cuda.synchronize(self.device)
         with torch.cuda.stream(self.stream):
             if grow_stage:
-                cap = max(int(nbytes * 1.25), 1 << 20)
+                cap = max(int(nbytes * 1.5), 1 << 20)      # few regrows: each one drains the device and re-pins
                 s.pinned = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
                 s.staging = torch.empty(cap, dtype=torch.uint8, device=self.device)
             if grow_b:

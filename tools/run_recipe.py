@@ -10,7 +10,9 @@ extra = sys.argv[2:]
 import finetune
 from neuspeech1_amd.synthetic import write_synthetic_dataset
 with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-    jl = write_synthetic_dataset(os.path.join(tmp, "data"), 512, ch_file=224, name="gwilliams", seed=6, min_len=600, max_len=3000)
+    schof = any(a == "--eeg_ch=273" for a in extra)      # the Schoffelen recipe (README.md:43-56): rows [28:301] of 301+
+    jl = write_synthetic_dataset(os.path.join(tmp, "data"), 512, ch_file=301 if schof else 224,
+                                 name="schoffelen" if schof else "gwilliams", seed=6, min_len=600, max_len=3000)
     rows = [l for l in open(jl)]
     with open(jl, "w") as f:            # 4096 list entries over the 512 recordings: one epoch covers the whole run
         for k in range(8):
