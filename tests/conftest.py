@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_is_built():
+    """In-tree incremental build before anything loads the library (a no-op when the .so is newer than every source;
+    hipcc cross-compiles gfx950 without a GPU).  The product path itself never builds: it fails loudly without the .so."""
+    from neuspeech1_amd.build import build
+    build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

@@ -2,17 +2,6 @@
 import os
 import re
 
-import pytest
-
-
-@pytest.fixture(scope="module", autouse=True)
-def _library_is_built():
-    """incremental in-tree build (a no-op when the .so is newer than every source): the symbol check then always runs
-    against the CURRENT sources, also in a tree where nobody has called __graft_entry__.build() yet"""
-    from neuspeech1_amd.build import build
-    build(verbose=False)
-
-
 def test_header_symbols_are_exported_and_bound():
     from neuspeech1_amd import lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
