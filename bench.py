@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the decode (eval tokens/s) leg")
     args = ap.parse_args()
 
+    from neuspeech1_amd import build as _b
+    if not os.path.exists(_b.LIB) and int(os.environ.get("RANK", "0")) == 0:
+        _b.build()      # the prebuilt in-tree .so normally travels with the tree (there is no CPU fallback to run instead)
     import torch
     import torch.distributed as dist
     from neuspeech1_amd import ops
