@@ -101,8 +101,13 @@ def main():
     args = ap.parse_args()
 
     from neuspeech1_amd import build as _b
-    if not os.path.exists(_b.LIB) and int(os.environ.get("RANK", "0")) == 0:
-        _b.build()      # the prebuilt in-tree .so normally travels with the tree (there is no CPU fallback to run instead)
+    if not os.path.exists(_b.LIB):      # the prebuilt in-tree .so normally travels with the tree (no CPU fallback exists)
+        if int(os.environ.get("RANK", "0")) == 0:
+            _b.build()
+        else:
+            t_end = time.time() + 600
+            while not os.path.exists(_b.LIB) and time.time() < t_end:
+                time.sleep(1.0)
     import torch
     import torch.distributed as dist
     from neuspeech1_amd import ops
