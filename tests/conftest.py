@@ -16,8 +16,13 @@ def pytest_configure(config):
 def _library_is_built():
     """In-tree incremental build before anything loads the library (a no-op when the .so is newer than every source;
     hipcc cross-compiles gfx950 without a GPU).  The product path itself never builds: it fails loudly without the .so."""
-    from neuspeech1_amd.build import build
-    build(verbose=False)
+    from neuspeech1_amd import build as b
+    try:
+        b.build(verbose=False)
+    except Exception as e:       # e.g. no compiler on the box: a prebuilt library that travelled with the tree still serves
+        if not os.path.exists(b.LIB):
+            raise
+        print(f"[conftest] incremental build failed ({e}); using the existing {b.LIB}")
 
 
 @pytest.fixture(scope="session")
