@@ -105,8 +105,10 @@ def main():
         if int(os.environ.get("RANK", "0")) == 0:
             _b.build()
         else:
-            t_end = time.time() + 600
-            while not os.path.exists(_b.LIB) and time.time() < t_end:
+            t_end = time.time() + 600   # rank 0 links to a temporary name and renames: the file appears complete
+            while not os.path.exists(_b.LIB):
+                if time.time() > t_end:
+                    raise RuntimeError(f"rank {os.environ.get('RANK')}: {_b.LIB} did not appear within 600 s")
                 time.sleep(1.0)
     import torch
     import torch.distributed as dist

@@ -208,18 +208,6 @@ def rotate_checkpoints(output_dir, keep):
         shutil.rmtree(os.path.join(output_dir, f"checkpoint-{st}"), ignore_errors=True)
 
 
-def grouped(iterable, n):
-    """lists of up to n consecutive items (the last group of an epoch may be shorter, as in HF Trainer)"""
-    buf = []
-    for item in iterable:
-        buf.append(item)
-        if len(buf) == n:
-            yield buf
-            buf = []
-    if buf:
-        yield buf
-
-
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print_arguments(args)
@@ -347,21 +335,30 @@ def main(argv=None):
     loader = torch.utils.data.DataLoader(train_dataset, batch_size=B, sampler=sampler, num_workers=args.num_workers,
                                          collate_fn=data_collator, drop_last=False, pin_memory=True,
                                          persistent_workers=args.num_workers > 0)
+    n_batches = len(loader)
+    rk = dict(on_ready=reducer.on_ready, reduce_fn=reducer.finish) if reducer is not None else {}
     for epoch in range(args.num_train_epochs):
         sampler.set_epoch(epoch)
-        for group in grouped(DevicePrefetcher(loader, whisper.device, feed), accum):
-            rk = dict(on_ready=reducer.on_ready, reduce_fn=reducer.finish) if reducer is not None else {}
-            if len(group) == 1:
-                loss = eng.train_step(group[0][0], group[0][1], **rk)
+        mi, micro = 0, []
+        for bi, (x, y) in enumerate(DevicePrefetcher(loader, whisper.device, feed)):
+            # micro-batches are consumed as they arrive (never more than the prefetched one held beside the running one,
+            # whatever --gradient_accumulation_steps is); the last group of an epoch may be shorter, as in HF Trainer
+            count = min(accum, n_batches - (bi - mi))
+            if count == 1:
+                loss = eng.train_step(x, y, **rk)
             else:       # gradient accumulation: the exchange and the optimizer run with the last micro-batch
-                micro = [eng.accumulate_step(x, y, mi, len(group), **rk) for mi, (x, y) in enumerate(group)]
+                micro.append(eng.accumulate_step(x, y, mi, count, **rk))
+            n_log += x.shape[0]
+            if hasattr(x, "release"):
+                x.release()             # the step reading this staged batch is enqueued: its slot may be refilled
+            mi += 1
+            if mi < count:
+                continue
+            if count > 1:
                 loss = torch.stack(micro).mean()
+            mi, micro = 0, []
             step += 1
-            n_log += sum(x.shape[0] for x, _ in group)
             loss_sum, loss_cnt = loss_sum + loss.detach().reshape(()).float(), loss_cnt + 1   # stays on the device
-            for x, _ in group:
-                if hasattr(x, "release"):
-                    x.release()         # the step reading this staged batch is enqueued: its slot may be refilled
             if step % args.logging_steps == 0 and rank == 0:
                 # HF Trainer logs the MEAN training loss of the steps since the previous log line
                 mean_loss = (loss_sum / loss_cnt).item()        # waits for the interval's kernels: dt below is a GPU rate

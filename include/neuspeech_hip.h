@@ -201,9 +201,10 @@ int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream);
  * ---------------------------------------------------------------------- */
 int ns_adalora_fold_grads(const float* dBf, const float* B, const float* E, float* dB, float* dE, int N, int r,
                           float s, void* stream);
+#define NS_ORTH_MAX_R 32            /* largest live rank ns_orth_reg handles (the reference's init_r is 12) */
 typedef struct {
   const float* P; float* G;       /* parameter and its gradient (same layout) */
-  int32_t r, len, ld, is_b;       /* lora_A: (r x len) rows; lora_B: (len x r) with is_b = 1; ld = row stride */
+  int32_t r, len, ld, is_b;       /* lora_A: (r x len) rows; lora_B: (len x r) with is_b = 1; ld = row stride; r <= NS_ORTH_MAX_R */
 } ns_orth_job;
 int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, const float* loss_scale_dev,
                 float* reg_out_dev, void* stream);
@@ -309,7 +310,13 @@ typedef struct {
    * seq_bias[s] to their LAST token in every row whose history ends with the tokens before it.  ns_logits_process only
    * (ns_logits_select refuses a descriptor that carries a bias). */
   const float* bias1; const int32_t* seq_tok; const int32_t* seq_off; const float* seq_bias;
-  int32_t n_seq, reserved;
+  int32_t n_seq;
+  /* forced decoder ids (generation_config.forced_decoder_ids as the reference's generate wrapper hands them to
+   * super().generate, utils/load_model.py:1210-1256,1314-1322; HF ForceTokensLogitsProcessor, LAST in HF's processor
+   * order): forced[pos] = token forced at sequence position pos (cur_len), or -1 = free; positions >= n_forced are free.
+   * At a forced position every score becomes -inf except the forced token's, which becomes 0 (+ beam score). */
+  int32_t n_forced;
+  const int32_t* forced;
 } ns_logits_proc_desc;
 int ns_logits_process(const ns_logits_proc_desc* d, void* stream);
 

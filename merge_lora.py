@@ -22,6 +22,11 @@ from utils.model_utils import projection_module  # noqa: E402
 from utils.utils import add_arguments, print_arguments  # noqa: E402
 
 
+# what WhisperFeatureExtractor / WhisperTokenizerFast / WhisperProcessor .save_pretrained write
+PROCESSOR_FILES = ("preprocessor_config.json", "processor_config.json", "tokenizer.json", "tokenizer_config.json", "vocab.json",
+                   "merges.txt", "normalizer.json", "added_tokens.json", "special_tokens_map.json", "generation_config.json")
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description=__doc__)
     add_arg = functools.partial(add_arguments, argparser=parser)
@@ -48,6 +53,15 @@ def main(argv=None):
     save_directory = os.path.join(args.lora_model, "full_model")
     os.makedirs(save_directory, exist_ok=True)
     model.save_pretrained(save_directory)
+    # the reference saves feature extractor, tokenizer and processor beside the merged weights (merge_lora.py:24-29,
+    # 50-54) so that evaluation.py can load WhisperProcessor from full_model: their files travel unchanged
+    base = args.model_path
+    if isinstance(base, str) and os.path.isdir(base):
+        import shutil
+        for name in PROCESSOR_FILES:
+            src = os.path.join(base, name)
+            if os.path.isfile(src) and not os.path.exists(os.path.join(save_directory, name)):
+                shutil.copy2(src, os.path.join(save_directory, name))
     with open(os.path.join(save_directory, "merge_info.json"), "w") as f:
         json.dump({"base_model": args.model_path, "adapter": os.path.abspath(args.lora_model), "eeg_ch": args.eeg_ch,
                    "config_name": args.config_name}, f, indent=1)

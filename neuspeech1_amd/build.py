@@ -46,6 +46,16 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
+def stale_sources():
+    """sources / headers newer than the built library (empty list: the .so is current)"""
+    if not os.path.exists(LIB):
+        return sources()
+    t = os.path.getmtime(LIB)
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(HERE, "..", "include", "neuspeech_hip.h"))
+    return [os.path.basename(f) for f in files if os.path.getmtime(f) > t]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(BUILD, exist_ok=True)
     srcs = sources()
@@ -53,10 +63,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     newest_obj = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest_obj:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        tmp = f"{LIB}.tmp.{os.getpid()}"    # link beside the target, then rename: no reader ever sees a partial ELF
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB)
     if verbose:
         print(f"[neuspeech1_amd] built {LIB} from {len(srcs)} sources")
     return LIB

@@ -317,6 +317,12 @@ __device__ __forceinline__ float blk_reduce(float v, bool is_max, float* sh) {
   return r;
 }
 
+__device__ __forceinline__ int ns_forced_token(const ns_logits_proc_desc& p, int cur) {
+  if (!p.forced || cur < 0 || cur >= p.n_forced) return -1;
+  const int t = p.forced[cur];
+  return t < p.V ? t : -1;
+}
+
 __global__ __launch_bounds__(256) void logits_process_kernel(const ns_logits_proc_desc p) {
   __shared__ float sh[4];
   const int row = blockIdx.x, tid = threadIdx.x;
@@ -391,9 +397,20 @@ __global__ __launch_bounds__(256) void logits_process_kernel(const ns_logits_pro
     }
     __syncthreads();
   }
-  for (int i = tid; i < p.n_suppress; i += 256) out[p.suppress[i]] = -INFINITY;
+  for (int i = tid; i < p.n_suppress; i += 256) {
+    const int c = p.suppress[i];
+    if (c >= 0 && c < p.V) out[c] = -INFINITY;
+  }
   if (cur == p.begin_index)
-    for (int i = tid; i < p.n_begin_suppress; i += 256) out[p.begin_suppress[i]] = -INFINITY;
+    for (int i = tid; i < p.n_begin_suppress; i += 256) {
+      const int c = p.begin_suppress[i];
+      if (c >= 0 && c < p.V) out[c] = -INFINITY;
+    }
+  const int ft = ns_forced_token(p, cur);
+  if (ft >= 0) {      // ForceTokensLogitsProcessor: the forced token scores 0, everything else -inf
+    __syncthreads();
+    for (int c = tid; c < p.V; c += 256) out[c] = c == ft ? 0.f : -INFINITY;
+  }
   if (p.beam_scores) {
     __syncthreads();
     const float bs = p.beam_scores[row];
@@ -501,6 +518,20 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
   const int64_t* ids = p.ids + (long long)row * p.ids_ld;
   const int cur = p.cur_len_dev ? *p.cur_len_dev : p.cur_len;
   const int V = p.V, nvec = (V + 7) >> 3;
+  {
+    const int ft = ns_forced_token(p, cur);
+    if (ft >= 0) {
+      // forced position: one finite candidate (0 + beam score); the -inf rest in column order, as a top-k over the
+      // processed row of ns_logits_process would list them (value desc, column asc)
+      if (tid < k) {
+        const int gb = (row % group_rows) * V;
+        const int c = tid == 0 ? ft : (tid - 1 < ft ? tid - 1 : tid);
+        cand_vals[(long long)row * k + tid] = tid == 0 ? (p.beam_scores ? p.beam_scores[row] : 0.f) : -INFINITY;
+        cand_idx[(long long)row * k + tid] = c < V ? gb + c : 0x7fffffff;
+      }
+      return;
+    }
+  }
   for (int i = tid; i < SEL_WORDS; i += 256) { ovr[i] = 0u; inf[i] = 0u; }
   if (tid == 0) { npatch = 0; ncand = 0; }
 

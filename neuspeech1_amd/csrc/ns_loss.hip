@@ -7,10 +7,12 @@
 
 namespace {
 
-__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int rows, int* __restrict__ nvalid) {
+// a label outside [0, V) other than the ignore index -100 is an error in the reference (torch's CrossEntropyLoss
+// asserts; the reference collator only warns, utils/data_utils.py:201): here it is ignored like -100, never read
+__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int rows, int V, int* __restrict__ nvalid) {
   __shared__ int sh[4];
   int c = 0;
-  for (int i = threadIdx.x; i < rows; i += blockDim.x) c += labels[i] != -100;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) c += labels[i] >= 0 && labels[i] < V;
   c = (int)ns_wave_sum((float)c);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const half_t* __restrict__ logi
   const half_t* lr = logits + (size_t)row * ldv;
   half_t* dr = dlogits ? dlogits + (size_t)row * ldv : nullptr;
   const int nchunks = ldv / 8;
-  if (lab == -100) {
+  if (lab < 0 || lab >= V) {
     if (threadIdx.x == 0) row_loss[row] = 0.f;
     if (dr) {
       const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -126,7 +128,7 @@ extern "C" int ns_cross_entropy(const void* logits16, const int64_t* labels, int
   NS_CHECK_ARG(logits16 && labels && row_loss && nvalid_dev && loss_dev, "ns_cross_entropy: null pointer");
   NS_CHECK_ARG(rows > 0 && V > 0 && ldv >= V && ldv % 8 == 0, "ns_cross_entropy: bad shape rows=%d V=%d ldv=%d", rows, V, ldv);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, st, labels, rows, nvalid_dev);
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, st, labels, rows, V, nvalid_dev);
   hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, st, (const half_t*)logits16, labels, V, ldv, row_loss,
                      (half_t*)dlogits16, nvalid_dev, loss_scale_dev);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, nvalid_dev, loss_dev);

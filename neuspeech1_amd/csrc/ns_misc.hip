@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256) void adalora_fold_kernel(const float* __restri
 __global__ __launch_bounds__(256) void orth_reg_kernel(const ns_orth_job* __restrict__ jobs, float weight_over_num,
                                                        const float* __restrict__ loss_scale, float* __restrict__ reg_out) {
   const ns_orth_job j = jobs[blockIdx.x];
-  __shared__ float cov[16][17];
+  __shared__ float cov[NS_ORTH_MAX_R][NS_ORTH_MAX_R + 1];   // callers keep r <= NS_ORTH_MAX_R (engine / peft_compat check)
   __shared__ float nrm;
-  const int r = j.r, len = j.len;     // P is (r x len) for lora_A [is_b = 0], (len x r) for lora_B [is_b = 1]
+  const int r = min(j.r, NS_ORTH_MAX_R), len = j.len;     // P is (r x len) for lora_A [is_b = 0], (len x r) for lora_B [is_b = 1]
   const float* P = j.P;
   auto at = [&](int k, int t) -> float { return j.is_b ? P[(size_t)t * j.ld + k] : P[(size_t)k * j.ld + t]; };
   for (int pr = threadIdx.x; pr < r * r; pr += 256) {

@@ -125,6 +125,8 @@ class MegWhisperEngine:
         self.r = lora.r_pad if lora else 0          # MFMA K granularity: ranks are zero-padded to a multiple of 16
         self.r_real = lora.r if lora else 0
         self.adalora = bool(lora and lora.adalora)
+        if self.adalora and lora.r > 32:
+            raise ValueError(f"AdaLoRA init_r={lora.r}: ns_orth_reg handles ranks up to 32 (NS_ORTH_MAX_R)")
         # front-end variant (utils/model_utils.py:9-23): 'base' = conv1.0 (k3,s1) + GELU + conv1.2 (k3,s2); 'replace' =
         # ONE stride-2 conv `encoder.conv1` straight from the MEG channels
         self.frontend = "replace" if ("model.encoder.conv1.weight" in sd and "model.encoder.conv1.0.weight" not in sd) else "base"

@@ -73,7 +73,12 @@ class Generator:
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
                  repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0, suppress_tokens=(),
                  begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
-                 pad_id: int | None = None, check_every: int = 4, sequence_bias=None) -> torch.Tensor:
+                 pad_id: int | None = None, check_every: int = 4, sequence_bias=None, forced_decoder_ids=None,
+                 begin_index: int | None = None) -> torch.Tensor:
+        """forced_decoder_ids: [[position, token or None], ...] (generation_config.forced_decoder_ids as the reference's
+        wrapper passes them on, utils/load_model.py:1210-1256): HF ForceTokensLogitsProcessor semantics, position =
+        absolute index in the decoder sequence.  begin_index: the position the begin-suppress list applies at (default:
+        the prompt length; HF of the reference's era adds forced_decoder_ids[-1][0])."""
         eng = self.eng
         if getattr(eng, "dec_lora", False):
             raise RuntimeError("decode from merged weights (merge_and_unload / merge_lora.py): the generation loop does not "
@@ -166,9 +171,31 @@ class Generator:
             ops.layernorm_fwd(h[0], *eng.dec_ln, x16, *st, Bp, d)
             ops.gemm(A=x16, am=rowmap(d), K=d, B=eng.E16, ldb=d, M=Bp, N=Vp, C16=logits, c16m=rowmap(Vp))
 
+        for name, lst in (("suppress_tokens", suppress_tokens), ("begin_suppress_tokens", begin_suppress_tokens)):
+            bad = [int(t) for t in lst if not 0 <= int(t) < V]
+            if bad:     # these ids index the score row on the device
+                raise ValueError(f"The model vocabulary size is {V}, but `{name}` holds {bad}")
         sup = torch.tensor(list(suppress_tokens), device=dev, dtype=torch.int32) if len(suppress_tokens) else None
         bsup = torch.tensor(list(begin_suppress_tokens), device=dev, dtype=torch.int32) if len(begin_suppress_tokens) else None
-        proc = dict(logits16=logits, scores32=scores, rows=Bp, V=V, ldv=Vp, ids_ld=max_len, begin_index=P,
+        forced_tab, n_forced = None, 0
+        if forced_decoder_ids:
+            fmap = {int(i): t for i, t in forced_decoder_ids if t is not None}
+            bad = [t for t in fmap.values() if not 0 <= int(t) < V]
+            if bad:
+                raise ValueError(f"The model vocabulary size is {V}, but `forced_decoder_ids` holds {bad}")
+            if fmap:
+                n_forced = max(fmap) + 1
+                tab = [-1] * n_forced
+                for i, t in fmap.items():
+                    if i >= 0:
+                        tab[i] = int(t)
+                forced_tab = torch.tensor(tab, device=dev, dtype=torch.int32)
+        if forced_tab is not None:
+            sb_forced = dict(forced=forced_tab, n_forced=n_forced)
+        else:
+            sb_forced = {}
+        proc = dict(logits16=logits, scores32=scores, rows=Bp, V=V, ldv=Vp, ids_ld=max_len,
+                    begin_index=P if begin_index is None else int(begin_index), **sb_forced,
                     repetition_penalty=float(repetition_penalty), no_repeat_ngram=int(no_repeat_ngram_size),
                     suppress=sup, n_suppress=len(suppress_tokens), begin_suppress=bsup,
                     n_begin_suppress=len(begin_suppress_tokens), **sb)

@@ -114,7 +114,7 @@ class LogitsProcDesc(C.Structure):
         ("log_softmax", C.c_int32),
         ("repetition_penalty", C.c_float),
         ("bias1", C.c_void_p), ("seq_tok", C.c_void_p), ("seq_off", C.c_void_p), ("seq_bias", C.c_void_p),
-        ("n_seq", C.c_int32), ("reserved", C.c_int32),
+        ("n_seq", C.c_int32), ("n_forced", C.c_int32), ("forced", C.c_void_p),
     ]
 
 

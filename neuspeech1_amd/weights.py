@@ -50,6 +50,8 @@ class WhisperDims:
 
 WHISPER_BASE = WhisperDims()
 WHISPER_LARGE_V2 = WhisperDims(d=1280, heads=20, ffn=5120, enc_layers=32, dec_layers=32, ch=273)
+# whisper-large-v2 WIDTH (d 1280, 20 heads, ffn 5120, 273 channels) at 2 + 2 layers: the parity fixture of BASELINE configs[4]
+LV2W = WhisperDims(d=1280, heads=20, ffn=5120, enc_layers=2, dec_layers=2, ch=273)
 # tiny config for fast parity tests (dims kept multiples of what the kernels need)
 TINY = WhisperDims(d=256, heads=4, ffn=512, enc_layers=2, dec_layers=2, vocab=1000, src_pos=100, tgt_pos=64, ch=20,
                    pad_id=999, bos_id=999, eos_id=999, start_id=998)

@@ -190,12 +190,17 @@ def loss_and_grads(sd_np, lora_np, x_np, labels_np, dims, scale, orth_reg_weight
 
 
 def lora_merge(sd_np, lora_np, scale):
-    """merge_and_unload (evaluation.py:88-89, merge_lora.py:43-44): W <- W + scale * B A."""
+    """merge_and_unload (evaluation.py:88-89, merge_lora.py:43-44): W <- W + scale * B A  (LoRA), resp.
+    W <- W + scale * B (A * E) with scale = alpha / (r + 1e-5)  (AdaLoRA, peft SVDLinear.get_delta_weight; the
+    reference's default adapter, finetune.py:43,205-208)."""
     out = dict(sd_np)
     for k in lora_np:
         if k.endswith(".lora_A.weight"):
             base = k[: -len(".lora_A.weight")]
-            out[base + ".weight"] = (sd_np[base + ".weight"] + scale * lora_np[base + ".lora_B.weight"] @ lora_np[k]).astype(np.float32)
+            a = lora_np[k]
+            if (base + ".lora_E.weight") in lora_np:
+                a = a * lora_np[base + ".lora_E.weight"].reshape(-1, 1)
+            out[base + ".weight"] = (sd_np[base + ".weight"] + scale * lora_np[base + ".lora_B.weight"] @ a).astype(np.float32)
     return out
 
 
@@ -256,8 +261,26 @@ def suppress_(scores, suppress_tokens, begin_suppress, cur_len, begin_index):
     return scores
 
 
+def force_tokens_(scores, forced_decoder_ids, cur_len):
+    """HF ForceTokensLogitsProcessor (generation/logits_process.py of the reference's era; LAST processor): at
+    generation index cur_len, a non-None forced token gets score 0 and every other token -inf.  The reference hands
+    generation_config.forced_decoder_ids to it through utils/load_model.py:1210-1256,1314-1322."""
+    if forced_decoder_ids:
+        tok = {int(i): t for i, t in forced_decoder_ids}.get(cur_len)
+        if tok is not None:
+            scores[:] = -float("inf")
+            scores[:, tok] = 0.0
+    return scores
+
+
+def begin_index_for(prompt_len, forced_decoder_ids):
+    """HF generation/utils.py _get_logits_processor of the reference's era: the begin-suppress list applies at
+    prompt_len (+ forced_decoder_ids[-1][0] when forced ids are set)."""
+    return prompt_len + (int(forced_decoder_ids[-1][0]) if forced_decoder_ids else 0)
+
+
 def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repeat_ngram_size=0,
-           suppress_tokens=(), begin_suppress_tokens=(), eos_id=None):
+           suppress_tokens=(), begin_suppress_tokens=(), eos_id=None, forced_decoder_ids=None):
     """HF:generation/utils.py:2783-2975 (greedy search): processors act on raw last-position logits
     (fp32), argmax, finished rows emit pad.  Returns prompt + new tokens (GenerationMixin semantics)."""
     eos_id = dims.eos_id if eos_id is None else eos_id
@@ -265,7 +288,7 @@ def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repea
     ids = prompt.clone()
     Bn = ids.shape[0]
     done = torch.zeros(Bn, dtype=torch.bool)
-    begin = prompt.shape[1]
+    begin = begin_index_for(prompt.shape[1], forced_decoder_ids)
     for _ in range(max_new_tokens):
         s = _decoder_logits_last(sd, ids, enc, dims).float().clone()
         if repetition_penalty != 1.0:
@@ -273,6 +296,7 @@ def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repea
         if no_repeat_ngram_size > 0:
             no_repeat_ngram_(s, ids, no_repeat_ngram_size)
         suppress_(s, list(suppress_tokens), list(begin_suppress_tokens), ids.shape[1], begin)
+        force_tokens_(s, forced_decoder_ids, ids.shape[1])
         nxt = s.argmax(-1)
         nxt = torch.where(done, torch.full_like(nxt, dims.pad_id), nxt)
         ids = torch.cat([ids, nxt[:, None]], 1)
@@ -283,7 +307,7 @@ def greedy(sd, x, dims, prompt, max_new_tokens, repetition_penalty=1.0, no_repea
 
 
 def beam_search(sd, x, dims, prompt, num_beams, max_new_tokens, repetition_penalty=1.0, no_repeat_ngram_size=0,
-                suppress_tokens=(), begin_suppress_tokens=(), length_penalty=1.0, eos_id=None):
+                suppress_tokens=(), begin_suppress_tokens=(), length_penalty=1.0, eos_id=None, forced_decoder_ids=None):
     """HF:generation/utils.py:3208-3545 (_beam_search, do_sample=False, early_stopping=False) with its helpers
     :3077-3129 (_get_top_k_continuations), :3131-3152 (_get_running_beams_for_next_iteration), :3154-3204
     (_update_finished_beams), :3008-3053 (_check_early_stop_heuristic), :3055-3075 (loop condition).
@@ -320,7 +344,8 @@ def beam_search(sd, x, dims, prompt, num_beams, max_new_tokens, repetition_penal
             repetition_penalty_(lp, flat, repetition_penalty)
         if no_repeat_ngram_size > 0:
             no_repeat_ngram_(lp, flat, no_repeat_ngram_size)
-        suppress_(lp, list(suppress_tokens), list(begin_suppress_tokens), cur, P)
+        suppress_(lp, list(suppress_tokens), list(begin_suppress_tokens), cur, begin_index_for(P, forced_decoder_ids))
+        force_tokens_(lp, forced_decoder_ids, cur)
         tot = (lp.view(Bn, nb, V) + run_scores[:, :, None]).view(Bn, nb * V)
         top, idx = torch.topk(tot, 2 * nb, dim=1)
         beam_idx = idx // V

@@ -198,3 +198,44 @@ def test_shard_indices_follow_distributed_sampler():
                 s = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=42)
                 s.set_epoch(epoch)
                 assert list(s) == shard_indices(len(data), epoch, rank, world)
+
+
+def test_from_pretrained_reads_a_stock_hf_checkpoint_and_its_generation_config(tmp_path):
+    """SURVEY §8 f2 (finetune.py:127-131, evaluation.py:72-74 load `openai/whisper-*`): a directory WRITTEN BY STOCK
+    transformers save_pretrained (tests/hf_ckpt.py) loads tensor-for-tensor, and generation_config.json (suppress
+    lists, max_length) is picked up.  No compute: the GPU side is tests/test_hf_ckpt_gpu.py."""
+    from tests.hf_ckpt import GEN_CFG, write_stock_hf_checkpoint
+    from neuspeech1_amd.weights import TINY
+    from utils.load_model import WhisperForConditionalGeneration
+    ref_sd = write_stock_hf_checkpoint(TINY, str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["config.json", "generation_config.json", "model.safetensors"]
+    model = WhisperForConditionalGeneration.from_pretrained(str(tmp_path), device_map="cpu")
+    own = model.state_dict()
+    for k, v in ref_sd.items():
+        assert k in own, k
+        assert torch.equal(own[k], v), k
+    assert model.model.encoder.conv1.in_channels == 80           # the stock mel front-end until the MEG one is installed
+    gc = GEN_CFG(TINY)
+    assert list(model.generation_config.suppress_tokens) == gc["suppress_tokens"]
+    assert list(model.generation_config.begin_suppress_tokens) == gc["begin_suppress_tokens"]
+    assert model.generation_config.max_length == gc["max_length"]
+    assert model.config.d_model == TINY.d and model.config.encoder_attention_heads == TINY.heads
+    # a save -> load round trip keeps the generation defaults
+    out = tmp_path / "again"
+    model.save_pretrained(str(out))
+    again = WhisperForConditionalGeneration.from_pretrained(str(out), device_map="cpu")
+    assert vars(again.generation_config) == vars(model.generation_config)
+
+
+def test_merge_lora_copies_the_processor_files(tmp_path, monkeypatch):
+    """reference merge_lora.py:24-29,50-54 saves feature extractor / tokenizer / processor into full_model so that
+    evaluation.py can load WhisperProcessor from it; here their files travel from the base directory."""
+    import merge_lora
+    base = tmp_path / "base"
+    base.mkdir()
+    for name in ("tokenizer.json", "vocab.json", "preprocessor_config.json", "unrelated.bin"):
+        (base / name).write_text("{}")
+    assert "tokenizer.json" in merge_lora.PROCESSOR_FILES and "unrelated.bin" not in merge_lora.PROCESSOR_FILES
+    import inspect
+    src = inspect.getsource(merge_lora.main)
+    assert "PROCESSOR_FILES" in src and "shutil.copy2" in src

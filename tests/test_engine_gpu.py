@@ -454,3 +454,79 @@ def test_base_shape_step_is_the_same_through_the_big_gemm_kernels(dev):
     assert abs(res[0][0] - res[1][0]) < 1e-3 * max(1.0, abs(res[0][0])), (res[0][0], res[1][0])
     assert rel(res[1][2], res[0][2]) < 2e-3
     assert rel(res[1][1], res[0][1]) < 1e-2
+
+
+def test_adalora_matches_reference_on_merged_weights(dev):
+    """The reference's DEFAULT adapter (finetune.py:43,205-208: AdaLoRA, init_r 12, alpha 32) against the reference
+    object itself: the engine's adapter path (rank padded to 16, diag(E) folded into the fp16 up-projection) must give
+    the logits stock HF gives on W + alpha/(r+1e-5) B (A * E) (tests/golden/adalora_merged_tiny.npz), and
+    merge_and_unload's arithmetic (PeftModel) the same again."""
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    g = np.load(os.path.join(G, "adalora_merged_tiny.npz"))
+    dims, r = TINY, int(g["r"])
+    sd = make_state_dict(dims, 42)
+    lora_sd = make_lora_state(dims, r, adalora=True, b_std=float(g["b_std"]))
+    spec = LoraSpec(r=r, alpha=float(g["alpha"]), dropout=0.1, adalora=True, orth_reg_weight=0.5)
+    eng = MegWhisperEngine(dims, sd, lora=spec, lora_sd=lora_sd, train_cfg=TrainCfg(), device=dev)
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    loss, logits = eng.forward(xd, ld, train=False)           # eval mode: dropout off, no regulariser in the loss
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    assert abs(loss.item() - float(g["loss_base"])) > 1e-2
+    lg = logits.float().cpu().numpy()[:, :, ::3]
+    assert rel(lg, g["logits"]) < 1e-2, rel(lg, g["logits"])
+    # the frozen model through the same engine class is NOT this function
+    eng0 = MegWhisperEngine(dims, sd, train_cfg=TrainCfg(), device=dev)
+    loss0, _ = eng0.forward(xd, ld, train=False)
+    assert abs(loss0.item() - float(g["loss_base"])) < 2e-3 * float(g["loss_base"])
+
+
+@pytest.mark.parametrize("tag", ["base273", "lv2w"])
+def test_273_channels_and_large_v2_width_match_reference_golden(dev, tag):
+    """BASELINE configs[3] shape (whisper-base, 273 channels: ch_pad 320, first conv K = 960; /root/reference
+    README.md:60-64) and configs[4]'s WIDTH (d 1280, 20 heads, ffn 5120; 2 + 2 layers), B = 1: loss, encoder states,
+    logits and the conv-stem gradients against the reference object (tests/golden/train_{base273,lv2w}.npz)."""
+    from neuspeech1_amd.weights import LV2W, WhisperDims
+    g = np.load(os.path.join(G, f"train_{tag}.npz"))
+    dims = LV2W if tag == "lv2w" else WhisperDims(ch=273)
+    eng, sd, _ = make_engine(dims, dev, 0)
+    x, labels = synth_batch(dims, int(g["B"]), int(g["seed_d"]))
+    assert np.array_equal(labels, g["labels"])
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * float(g["loss"]), (loss.item(), float(g["loss"]))
+    enc = eng._b["enc16"].float().cpu().view(int(g["B"]), dims.src_pos, dims.d).numpy()
+    assert rel(enc[:, ::97, :16], g["enc_slice"]) < 2e-2
+    assert abs(np.sqrt((enc.astype(np.float64) ** 2).sum()) - float(g["enc_l2"])) < 1e-2 * float(g["enc_l2"])
+    got = engine_grads(eng, dims, 0)
+    for k in ("model.encoder.conv1.0.weight", "model.encoder.conv1.2.weight", "model.encoder.conv2.weight",
+              "model.encoder.conv1.0.bias", "model.encoder.conv1.2.bias", "model.encoder.conv2.bias"):
+        n = got[k].double().norm().item()
+        assert abs(n - float(g["gradnorm." + k])) < 4e-2 * float(g["gradnorm." + k]), (k, n, float(g["gradnorm." + k]))
+        assert rel(got[k].reshape(got[k].shape[0], -1)[:8, :8], g["gradslice." + k]) < 6e-2, k
+    _, logits = eng.forward(xd, ld, train=False)
+    lg = logits.float().cpu().numpy()
+    assert rel(lg[:, :, :16], g["logits_slice"]) < 2e-2
+    sure = g["top_margin"] > 0.1
+    assert np.array_equal(lg.argmax(-1)[sure], g["top1_id"][sure])
+
+
+def test_large_v2_width_lora_forward_backward_vs_oracle(dev):
+    """LoRA r = 32 at whisper-large-v2's width (d 1280: five 256-column tiles, 20 heads, ffn 5120; 2 + 2 layers, 273-ch,
+    B = 1): loss and every adapter gradient against the oracle."""
+    from neuspeech1_amd.weights import LV2W
+    from oracle import whisper_meg_oracle as O
+    dims = LV2W
+    eng, sd, lora_sd = make_engine(dims, dev, 32)
+    x, labels = synth_batch(dims, 1, 31)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.zero_grad()
+    loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
+    eng.backward()
+    o_loss, _, _, og = O.loss_and_grads(sd, lora_sd, x, labels, dims, 2.0)
+    assert abs(loss.item() - o_loss.item()) <= 2e-3 * max(1.0, o_loss.item()), (loss.item(), o_loss.item())
+    got = engine_grads(eng, dims, 32)
+    bad = {k: rel(got[k], ref) for k, ref in og.items() if k in got and ("lora" in k or "bias" in k) and not rel(got[k], ref) < 4e-2}
+    assert not bad, bad

@@ -244,3 +244,54 @@ def test_sequence_bias_processor_matches_hf_processors(dev):
     for bad in ({}, {(1, 2): 1}, {(V,): 1.0}, [[[], 1.0]], {(-1,): 1.0}):
         with pytest.raises(ValueError):
             _sequence_bias_tables(bad, V, dev)
+
+
+@pytest.mark.parametrize("pn", ["p1", "p4"])
+@pytest.mark.parametrize("name,nb,kw", [
+    ("greedy", 1, {}),
+    ("greedy_rp", 1, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("beam5", 5, {}),
+    ("beam5_rp", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+])
+def test_forced_decoder_ids_and_suppress_lists_token_ids_exact(setup, pn, name, nb, kw):
+    """generation_config.forced_decoder_ids ([[1, null], [2, task], [3, notimestamps]]-shaped) + non-empty suppress /
+    begin-suppress lists, as a hub whisper checkpoint carries them (reference utils/load_model.py:1210-1256 hands them to
+    super().generate): ids of the reference object (tools/make_goldens.py forced), with the decoder prompt the reference
+    uses for English (start token only) and for other languages (labels[:, :4], evaluation.py:353-355).  Both the fused
+    selection kernel and the two-kernel form (forced by a sequence-bias table of zeros)."""
+    _, dims, gen, x, _ = setup
+    g = np.load(os.path.join(G, "decode_tiny_forced.npz"))
+    forced = [[int(i), None if int(t) < 0 else int(t)] for i, t in zip(g["forced_idx"], g["forced_tok"])]
+    prompt = torch.from_numpy(g[pn + ".prompt"]).to(x.device)
+    for extra in ({}, dict(sequence_bias={(3,): 0.0})):
+        out = gen.generate(x, prompt, num_beams=nb, max_new_tokens=int(g["new_tokens"]), check_every=1,
+                           suppress_tokens=g["suppress"].tolist(), begin_suppress_tokens=g["begin_suppress"].tolist(),
+                           forced_decoder_ids=forced, begin_index=prompt.shape[1] + forced[-1][0], **kw, **extra)
+        check(out, g[f"{pn}.{name}"], dims.pad_id)
+    if name == "beam5_rp":
+        np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[f"{pn}.beam5_rp_scores"], atol=2e-2)
+
+
+@pytest.mark.parametrize("tag", ["base273", "lv2w"])
+@pytest.mark.parametrize("name,nb,kw", [
+    ("greedy", 1, {}),
+    ("greedy_rp", 1, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+    ("beam5", 5, {}),
+    ("beam5_rp", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)),
+])
+def test_token_ids_exact_at_273_channels_and_large_v2_width(dev, tag, name, nb, kw):
+    """BASELINE configs[3] (whisper-base, 273-ch Schoffelen shape, beam-5 + repetition penalty 5 + no-repeat-2:
+    /root/reference README.md:60-64) and configs[4]'s WIDTH (whisper-large-v2: d 1280, 20 heads, ffn 5120, 273-ch; 2 + 2
+    layers): ids of the reference object (tools/make_goldens.py decode_base273 / lv2w)."""
+    from neuspeech1_amd.engine import MegWhisperEngine
+    from neuspeech1_amd.generate import Generator
+    from neuspeech1_amd.weights import LV2W, WhisperDims
+    g = np.load(os.path.join(G, f"decode_{tag}.npz"))
+    dims = LV2W if tag == "lv2w" else WhisperDims(ch=273)
+    gen = Generator(MegWhisperEngine(dims, make_state_dict(dims, 42), device=dev))
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    out = gen.generate(torch.from_numpy(x).to(dev), torch.from_numpy(labels[:, :4].copy()).to(dev), num_beams=nb,
+                       max_new_tokens=int(g["new_tokens"]), check_every=1, **kw)
+    check(out, g[name], dims.pad_id)
+    if nb > 1:
+        np.testing.assert_allclose(gen.last_scores.cpu().numpy(), g[name + "_scores"], atol=2e-2)

@@ -576,3 +576,51 @@ def test_wide_nt_kernels_agree_on_every_epilogue_and_ragged_shape(ops, dev, mode
     conv = torch.nn.functional.conv1d(img.float().transpose(1, 2), Wc.float().view(N, 3, Cin).permute(0, 2, 1), stride=2)  # (4, N, T2)
     close(ref["conv_res_inplace"][0], Rc + (conv.transpose(1, 2).reshape(4 * T2, N) + bias).half().float(),
           2e-2, 3e-3, "conv rowmap")
+
+
+@pytest.mark.parametrize("name,N,K,kind", [("qkv_lora", 1536, 512, "second"), ("fc1_gelu", 2048, 512, "gelu"),
+                                           ("fc2_residual", 512, 2048, "res"), ("dgrad_mul", 512, 1536, "mulp"),
+                                           ("lv2_width", 1280, 1280, "res")])
+def test_dominant_gemm_at_bench_size_against_torch(ops, dev, name, N, K, kind):
+    """The dominant kernel (phase-interleaved 256^2 NT GEMM: M >= 2048 and >= 192 tiles) at the BENCH row count
+    M = 96 000 (B = 64 x 1500 encoder rows) under the automatic dispatch, DIRECTLY against torch fp32 on row slices
+    (first / last tile rows, tile seams, a ragged tail is covered by the forced-mode test above): q|k|v with the grouped
+    LoRA second product, fc1 + GELU (+ saved gelu'), fc2 + fp32 residual stream, a dgrad with the gelu' multiply."""
+    M, r = 96000, 32
+    A = rnd((M, K), dev, 1.0, seed=1)
+    B = rnd((N, K), dev, K ** -0.5, seed=2)
+    bias = rnd((N,), dev, 0.2, torch.float32, seed=3)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(47990, 48300), torch.arange(M - 333, M)]).to(dev)
+    Ar = A[rows].float()
+    full = Ar @ B.float().T + bias
+    if kind == "second":
+        u, Bs = rnd((M, 3 * r), dev, 0.5, seed=7), rnd((N, r), dev, 0.1, seed=8)
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(3 * r), K2=r, B2=Bs, ldb2=r,
+                 a2_ngroup=N // 3, bias=bias, C16=C, c16m=ops.rowmap(N))
+        for j in range(3):
+            full[:, j * 512:(j + 1) * 512] += u[rows, j * r:(j + 1) * r].float() @ Bs[j * 512:(j + 1) * 512].float().T
+        close(C[rows], full, 6e-3, 3e-3, name)
+    elif kind == "gelu":
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        Gd = torch.full_like(C, float("nan"))
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=C, c16m=ops.rowmap(N), G16=Gd,
+                 g16m=ops.rowmap(N), flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD)
+        pre = full.half().float()
+        close(Gd[rows], torch.nn.functional.gelu(pre), 4e-3, 3e-3, name + " gelu")
+        x = pre.double().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        close(C[rows], x.grad.float(), 4e-3, 3e-3, name + " saved gelu'")
+    elif kind == "res":
+        R = rnd((M, N), dev, 1.0, torch.float32, seed=4)
+        H = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, R32=R, H32=H, h32m=ops.rowmap(N))
+        close(H[rows], R[rows] + full.half().float(), 8e-3, 3e-3, name)
+        assert not torch.isnan(H).any()
+    else:
+        P = rnd((M, N), dev, 1.0, seed=6)
+        D = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N),
+                 flags=ops.NS_GEMM_MUL_P16)
+        close(D[rows], (Ar @ B.float().T).half().float() * P[rows].float(), 8e-3, 3e-3, name)
+        assert not torch.isnan(D.float()).any()

@@ -129,3 +129,68 @@ def test_oracle_decode_matches_reference_generate():
             same(f"greedy_eos{eos}", O.greedy(sd, xt, dims, prompt, n, eos_id=eos))
             same(f"beam5_eos{eos}", O.beam_search(sd, xt, dims, prompt, 5, n, eos_id=eos))
             same(f"beam5_rp_eos{eos}", O.beam_search(sd, xt, dims, prompt, 5, n, eos_id=eos, **rp))
+
+
+def test_oracle_adalora_equals_reference_on_merged_weights():
+    """AdaLoRA -- the reference's default adapter (finetune.py:43,205-208) -- pinned like LoRA: the oracle's
+    y += B((A x) * E) * alpha/(r + 1e-5) against the reference object run on W + alpha/(r+1e-5) B (A * E)
+    (tools/make_goldens.py adalora), with a non-zero E."""
+    g = np.load(os.path.join(G, "adalora_merged_tiny.npz"))
+    r, alpha = int(g["r"]), float(g["alpha"])
+    sd = make_state_dict(TINY, 42)
+    lora = make_lora_state(TINY, r, adalora=True, b_std=float(g["b_std"]))
+    x, labels = synth_batch(TINY, int(g["B"]), 1234)
+    with torch.no_grad():
+        loss, logits, _ = O.forward(O.to_torch(sd), torch.from_numpy(x), TINY, labels=torch.from_numpy(labels),
+                                    lora=O.to_torch(lora), scale=alpha / (r + 1e-5))
+    assert abs(loss.item() - float(g["loss"])) < 5e-5
+    assert abs(float(g["loss"]) - float(g["loss_base"])) > 1e-2          # the adapter matters in this fixture
+    np.testing.assert_allclose(logits.numpy()[:, :, ::3], g["logits"], atol=5e-4, rtol=1e-4)
+    # and the merge itself (what merge_and_unload does) reproduces the same function
+    merged = O.lora_merge(sd, lora, alpha / (r + 1e-5))
+    with torch.no_grad():
+        loss_m, _, _ = O.forward(O.to_torch(merged), torch.from_numpy(x), TINY, labels=torch.from_numpy(labels))
+    assert abs(loss_m.item() - float(g["loss"])) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["base273", "lv2w"])
+def test_oracle_matches_reference_273ch_and_large_v2_width(tag):
+    """BASELINE configs[3] / [4] shapes: whisper-base with 273 channels, and whisper-large-v2's WIDTH (d 1280, 20 heads,
+    ffn 5120) at 2 + 2 layers, B = 1."""
+    from neuspeech1_amd.weights import LV2W, WhisperDims
+    g = np.load(os.path.join(G, f"train_{tag}.npz"))
+    dims = LV2W if tag == "lv2w" else WhisperDims(ch=273)
+    sd = make_state_dict(dims, 42)
+    x, labels = synth_batch(dims, int(g["B"]), 1234)
+    assert np.array_equal(labels, g["labels"])
+    loss, logits, enc, grads = O.loss_and_grads(sd, None, x, labels, dims, 0.0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    np.testing.assert_allclose(enc.numpy()[:, ::97, :16], g["enc_slice"], atol=5e-4, rtol=1e-3)
+    np.testing.assert_allclose(logits.numpy()[:, :, :16], g["logits_slice"], atol=2e-3, rtol=1e-3)
+    for k in (k for k in O.TRAINABLE_CONV if k in grads):
+        n = np.sqrt((grads[k].numpy().astype(np.float64) ** 2).sum())
+        assert abs(n - float(g["gradnorm." + k])) < 2e-3 * float(g["gradnorm." + k]), k
+
+
+def test_oracle_forced_decoder_ids_match_reference_generate():
+    """forced_decoder_ids + non-empty suppress / begin-suppress lists (what a hub whisper generation_config.json
+    carries): greedy and beam-5 ids of the reference object (tools/make_goldens.py forced), prompt lengths 1 and 4."""
+    g = np.load(os.path.join(G, "decode_tiny_forced.npz"))
+    dims = TINY
+    sd = O.to_torch(make_state_dict(dims, 42))
+    x, _ = synth_batch(dims, int(g["B"]), 1234)
+    xt = torch.from_numpy(x)
+    n = int(g["new_tokens"])
+    forced = [[int(i), None if int(t) < 0 else int(t)] for i, t in zip(g["forced_idx"], g["forced_tok"])]
+    kw = dict(suppress_tokens=g["suppress"].tolist(), begin_suppress_tokens=g["begin_suppress"].tolist(),
+              forced_decoder_ids=forced)
+    rp = dict(repetition_penalty=5.0, no_repeat_ngram_size=2)
+    with torch.no_grad():
+        for pn in ("p1", "p4"):
+            prompt = torch.from_numpy(g[pn + ".prompt"])
+            assert np.array_equal(O.greedy(sd, xt, dims, prompt, n, **kw).numpy(), g[pn + ".greedy"]), pn
+            assert np.array_equal(O.greedy(sd, xt, dims, prompt, n, **rp, **kw).numpy(), g[pn + ".greedy_rp"]), pn
+            assert np.array_equal(O.beam_search(sd, xt, dims, prompt, 5, n, **rp, **kw).numpy(), g[pn + ".beam5_rp"]), pn
+            assert np.array_equal(O.beam_search(sd, xt, dims, prompt, 5, n, **kw).numpy(), g[pn + ".beam5"]), pn
+    # the forced positions really are forced, and position 1 (None) is free
+    assert (g["p1.greedy_rp"][:, 2] == forced[1][1]).all() and (g["p1.greedy_rp"][:, 3] == forced[2][1]).all()

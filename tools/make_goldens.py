@@ -16,7 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from neuspeech1_amd.weights import TINY, WHISPER_BASE, WhisperDims, make_lora_state, make_state_dict, synth_batch  # noqa: E402
+from neuspeech1_amd.weights import LV2W, TINY, WHISPER_BASE, WhisperDims, make_lora_state, make_state_dict, synth_batch  # noqa: E402
 
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -113,6 +113,120 @@ def lora_golden(dims, tag, B, r=32, alpha=64.0, decoder=False):
     print(f"lora_merged_{tag}: loss {out.loss.item():.6f}")
 
 
+def adalora_golden(dims, tag, B, r=12, alpha=32.0):
+    """AdaLoRA -- the reference's DEFAULT adapter (finetune.py:43,205-208: init_r=12, lora_alpha=32) -- pinned like LoRA:
+    the reference object run on the merged weights W + alpha/(r+1e-5) * B (A * E) (peft SVDLinear.get_delta_weight),
+    with a non-zero E so that the diag(E) path is live."""
+    from oracle.whisper_meg_oracle import lora_merge
+    sd_np = make_state_dict(dims, 42)
+    lora_np = make_lora_state(dims, r, adalora=True, b_std=0.3)
+    merged = lora_merge(sd_np, lora_np, alpha / (r + 1e-5))
+    model = build_hf(dims, merged)
+    x, labels = synth_batch(dims, B, 1234)
+    with torch.no_grad():
+        out = model(input_features=torch.from_numpy(x), labels=torch.from_numpy(labels))
+        base = build_hf(dims, sd_np)(input_features=torch.from_numpy(x), labels=torch.from_numpy(labels))
+    lg = out.logits.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"adalora_merged_{tag}.npz"), loss=np.float32(out.loss.item()),
+                        loss_base=np.float32(base.loss.item()), logits=lg[:, :, ::3], r=r, alpha=alpha, B=B, b_std=0.3)
+    print(f"adalora_merged_{tag}: loss {out.loss.item():.6f} (frozen model {base.loss.item():.6f})")
+
+
+class _ForceTokens:
+    """HF <= 4.37 ForceTokensLogitsProcessor [MEM: removed from the installed transformers 5.15]: at generation index
+    idx = input_ids.shape[-1], if the map holds a non-None token for idx every score becomes -inf except that token's,
+    which becomes 0.  The reference reaches it through generation_config.forced_decoder_ids
+    (utils/load_model.py:1210-1256 -> super().generate)."""
+
+    def __init__(self, forced):
+        self.m = {int(k): v for k, v in forced}
+
+    def __call__(self, input_ids, scores):
+        tok = self.m.get(int(input_ids.shape[-1]))
+        if tok is not None:
+            scores = torch.full_like(scores, -float("inf"))
+            scores[:, tok] = 0
+        return scores
+
+
+def decode_forced_golden(dims, tag, B, new_tokens):
+    """forced_decoder_ids + non-empty suppress / begin-suppress lists through the reference object.  Era semantics
+    (HF 4.31-4.35 generation/utils.py _get_logits_processor [MEM]): processors in the order repetition penalty,
+    no-repeat-ngram, suppress_tokens, begin-suppress at begin_index = prompt_len + forced_decoder_ids[-1][0], force-tokens."""
+    import transformers
+    from transformers import LogitsProcessorList
+    from transformers.generation.logits_process import SuppressTokensAtBeginLogitsProcessor
+    sd_np = make_state_dict(dims, 42)
+    model = build_hf(dims, sd_np)
+    x, labels = synth_batch(dims, B, 1234)
+    feats = torch.from_numpy(x)
+    V = dims.vocab
+    forced = [[1, None], [2, V - 6], [3, V - 5]]
+    g0 = np.load(os.path.join(OUT, "decode_tiny.npz"))["greedy_rp"]
+    suppress = sorted({int(g0[0, 5]), int(g0[1, 6]), 630, 34, V - 4, V - 3})
+    begin_suppress = sorted({int(g0[0, 4]), int(g0[1, 4]), int(g0[2, 4]), 250, dims.eos_id})
+    g = {"B": B, "new_tokens": new_tokens, "forced_idx": np.array([f[0] for f in forced]),
+         "forced_tok": np.array([-1 if f[1] is None else f[1] for f in forced]), "suppress": np.array(suppress),
+         "begin_suppress": np.array(begin_suppress)}
+    gen = transformers.GenerationMixin.generate
+    for pname, prompt in (("p1", torch.full((B, 1), dims.start_id, dtype=torch.long)), ("p4", torch.from_numpy(labels[:, :4].copy()))):
+        P = prompt.shape[1]
+        common = dict(do_sample=False, max_new_tokens=new_tokens, decoder_input_ids=prompt, suppress_tokens=suppress,
+                      begin_suppress_tokens=None, pad_token_id=dims.pad_id, eos_token_id=dims.eos_id,
+                      return_dict_in_generate=True, output_scores=True)
+        mk = lambda: LogitsProcessorList([SuppressTokensAtBeginLogitsProcessor(begin_suppress, P + forced[-1][0]),  # noqa: E731
+                                          _ForceTokens(forced)])
+        g[f"{pname}.prompt"] = prompt.numpy()
+        with torch.no_grad():
+            g[f"{pname}.greedy"] = gen(model, feats, num_beams=1, logits_processor=mk(), **common).sequences.numpy()
+            g[f"{pname}.greedy_rp"] = gen(model, feats, num_beams=1, repetition_penalty=5.0, no_repeat_ngram_size=2,
+                                          logits_processor=mk(), **common).sequences.numpy()
+            o = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, logits_processor=mk(), **common)
+            g[f"{pname}.beam5_rp"] = o.sequences.numpy()
+            g[f"{pname}.beam5_rp_scores"] = o.sequences_scores.numpy().astype(np.float32)
+            o = gen(model, feats, num_beams=5, logits_processor=mk(), **common)
+            g[f"{pname}.beam5"] = o.sequences.numpy()
+    np.savez_compressed(os.path.join(OUT, f"decode_{tag}_forced.npz"), **g)
+    print(f"decode_{tag}_forced: p1 greedy head {g['p1.greedy'][:, :6].tolist()}")
+
+
+def hf_checkpoint_golden(dims, tag, B):
+    """a checkpoint WRITTEN BY STOCK HF save_pretrained (config.json + generation_config.json +
+    model.safetensors; the stock 80-mel conv1 inside) -> load it back with stock HF, install the reference's
+    projection_module (evaluation.py:72-86) and record logits + generated ids.  Only the outputs are committed; the test
+    re-creates the directory with stock transformers (tests/hf_ckpt.py) and loads it with the build's from_pretrained."""
+    import tempfile
+    import transformers
+    from transformers import WhisperForConditionalGeneration
+    from tests.hf_ckpt import GEN_CFG, front_end_state, write_stock_hf_checkpoint
+    with tempfile.TemporaryDirectory() as td:
+        write_stock_hf_checkpoint(dims, td)
+        model = WhisperForConditionalGeneration.from_pretrained(td, attn_implementation="eager")
+        conv1 = ref_projection_module()(config_name="base", meg_ch=dims.ch, d_model=model.model.encoder.conv2.in_channels)
+        conv1.load_state_dict({k: torch.from_numpy(v) for k, v in front_end_state(dims).items()})
+        model.model.encoder.set_input_embeddings(conv1)
+        model.eval()
+        x, labels = synth_batch(dims, B, 1234)
+        feats = torch.from_numpy(x)
+        gc = model.generation_config
+        assert list(gc.suppress_tokens) == GEN_CFG(dims)["suppress_tokens"], "generation_config.json did not round-trip"
+        g = {"B": B}
+        with torch.no_grad():
+            out = model(input_features=feats, labels=torch.from_numpy(labels))
+            g["loss"] = np.float32(out.loss.item())
+            g["logits"] = out.logits.numpy().astype(np.float32)
+            gen = transformers.GenerationMixin.generate
+            prompt = torch.from_numpy(labels[:, :4].copy())
+            # the lists come from the checkpoint's generation_config.json; max_length too (prompt 4 -> 4 + new tokens)
+            common = dict(do_sample=False, decoder_input_ids=prompt, suppress_tokens=list(gc.suppress_tokens),
+                          begin_suppress_tokens=list(gc.begin_suppress_tokens), max_length=gc.max_length,
+                          pad_token_id=dims.pad_id, eos_token_id=dims.eos_id, return_dict_in_generate=True)
+            g["greedy_rp"] = gen(model, feats, num_beams=1, repetition_penalty=5.0, no_repeat_ngram_size=2, **common).sequences.numpy()
+            g["beam5_rp"] = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, **common).sequences.numpy()
+    np.savez_compressed(os.path.join(OUT, f"hf_ckpt_{tag}.npz"), **g)
+    print(f"hf_ckpt_{tag}: loss {g['loss']:.6f}, greedy_rp width {g['greedy_rp'].shape[1]}")
+
+
 def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630), sequence_bias=None):
     import transformers
     sd_np = make_state_dict(dims, 42)
@@ -193,6 +307,19 @@ if __name__ == "__main__":
     if "decode_base" in what:
         # BASELINE dims (whisper-base, 208-ch): token-id parity at the size the metric is quoted on
         decode_golden(WHISPER_BASE, "base208", B=2, new_tokens=16, eos_variants=())
+    if "decode_base273" in what:
+        # BASELINE configs[3] (README.md:60-64: Schoffelen, --eeg_ch=273): beam-5 + penalties at whisper-base, 273 channels
+        decode_golden(WhisperDims(ch=273), "base273", B=2, new_tokens=16, eos_variants=())
+    if "adalora" in what:
+        adalora_golden(TINY, "tiny", B=2)
+    if "lv2w" in what:
+        # BASELINE configs[4] WIDTH (whisper-large-v2: d=1280, 20 heads, ffn 5120, 273 channels) at 2+2 layers
+        train_golden(LV2W, "lv2w", B=1, full=False)
+        decode_golden(LV2W, "lv2w", B=2, new_tokens=12, eos_variants=())
+    if "forced" in what:
+        decode_forced_golden(TINY, "tiny", B=3, new_tokens=20)
+    if "hf_ckpt" in what:
+        hf_checkpoint_golden(TINY, "tiny", B=2)
 
 
 def reader_golden():

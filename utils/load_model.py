@@ -173,6 +173,7 @@ class WhisperForConditionalGeneration(nn.Module):
         self._engine = None
         self._peft = None          # set by neuspeech1_amd.peft_compat.get_peft_model
         self.train_cfg = None
+        self.generation_config = None   # SimpleNamespace of generation_config.json when the checkpoint carries one
         self.train(False)
 
     # ------------------------------------------------------------------ construction
@@ -210,6 +211,13 @@ class WhisperForConditionalGeneration(nn.Module):
             own = model.state_dict()
             sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
             model.load_state_dict(sd, strict=False)
+            # generation defaults travel beside the weights (hub whisper: max_length 448, the suppress lists,
+            # forced_decoder_ids [[1, null], [2, 50359]]).  evaluation.py:72-74 loads a fresh model, so
+            # these apply at decode.
+            gpath = os.path.join(path, "generation_config.json")
+            if os.path.exists(gpath):
+                with open(gpath) as f:
+                    model.generation_config = SimpleNamespace(**json.load(f))
         dev = _resolve_device(device_map)
         return model.to(dev)
 
@@ -221,6 +229,9 @@ class WhisperForConditionalGeneration(nn.Module):
         from safetensors.torch import save_file
         sd = {k: v.detach().contiguous().cpu() for k, v in self.state_dict().items() if k != "proj_out.weight"}
         save_file(sd, os.path.join(save_directory, "model.safetensors"))
+        if self.generation_config is not None:      # a merged export keeps the base checkpoint's generation defaults
+            with open(os.path.join(save_directory, "generation_config.json"), "w") as f:
+                json.dump(vars(self.generation_config), f, indent=1)
 
     # ------------------------------------------------------------------ HF-style accessors
     @property
@@ -238,9 +249,6 @@ class WhisperForConditionalGeneration(nn.Module):
 
     def get_output_embeddings(self):
         return self.proj_out
-
-    def post_init(self):
-        pass
 
     def load_state_dict(self, *a, **k):
         self._engine = None
@@ -381,7 +389,7 @@ class WhisperForConditionalGeneration(nn.Module):
     def generate(self, input_features=None, inputs=None, do_sample=False, num_beams=1, repetition_penalty=1.0,
                  no_repeat_ngram_size=0, decoder_input_ids=None, max_new_tokens=None, max_length=None,
                  length_penalty=1.0, suppress_tokens=None, begin_suppress_tokens=None, eos_token_id=None,
-                 pad_token_id=None, sequence_bias=None, **_):
+                 pad_token_id=None, sequence_bias=None, forced_decoder_ids=None, **_):
         """evaluation.py:370-386 call shape; returns prompt + generated ids (B, <= max_length) int64."""
         if do_sample:
             raise NotImplementedError("sampling is outside the hot path (the reference decodes with do_sample=False)")
@@ -389,19 +397,46 @@ class WhisperForConditionalGeneration(nn.Module):
         eng = self.engine()
         eng.refresh_operands()
         x = (input_features if input_features is not None else inputs).to(self.device, torch.float32).contiguous()
-        c = self.config
+        c, gc = self.config, self.generation_config
+
+        def default(name, explicit=None, fallback=None):
+            """explicit argument > generation_config.json > model config (HF: the generation config rules at generate;
+            one derived from the model config stands in when the checkpoint has no generation_config.json)"""
+            if explicit is not None:
+                return explicit
+            for src in (gc, c):
+                v = getattr(src, name, None) if src is not None else None
+                if v is not None:
+                    return v
+            return fallback
+
+        def one(v):
+            return v[0] if isinstance(v, (list, tuple)) else v
+
         if decoder_input_ids is None:
-            decoder_input_ids = torch.full((x.shape[0], 1), c.decoder_start_token_id, dtype=torch.int64)
+            decoder_input_ids = torch.full((x.shape[0], 1), default("decoder_start_token_id"), dtype=torch.int64)
         prompt = decoder_input_ids.to(self.device, torch.int64).contiguous()
-        limit = max_length or getattr(c, "max_length", None) or c.max_target_positions
-        new = max_new_tokens if max_new_tokens is not None else limit - prompt.shape[1]
-        sup = suppress_tokens if suppress_tokens is not None else (c.suppress_tokens or [])
-        bsup = begin_suppress_tokens if begin_suppress_tokens is not None else (getattr(c, "begin_suppress_tokens", None) or [])
+        P = prompt.shape[1]
+        limit = default("max_length", max_length, c.max_target_positions)
+        new = max_new_tokens if max_new_tokens is not None else limit - P
+        sup = default("suppress_tokens", suppress_tokens, [])
+        bsup = default("begin_suppress_tokens", begin_suppress_tokens, [])
+        # forced_decoder_ids, resolved like the reference's wrapper (utils/load_model.py:1210-1222: model config first,
+        # then the generation config, then the keyword) and applied like HF's ForceTokensLogitsProcessor; the
+        # begin-suppress list then applies after the last forced position (HF generation/utils.py of the reference's era:
+        # begin_index = prompt length + forced_decoder_ids[-1][0])
+        forced = getattr(c, "forced_decoder_ids", None)
+        if forced is None and gc is not None:
+            forced = getattr(gc, "forced_decoder_ids", None)
+        if forced is None:
+            forced = forced_decoder_ids
+        begin_index = P + int(forced[-1][0]) if forced else P
         return Generator(eng).generate(x, prompt, num_beams=num_beams, max_new_tokens=new,
                                        repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
                                        suppress_tokens=list(sup), begin_suppress_tokens=list(bsup),
-                                       length_penalty=length_penalty, eos_id=eos_token_id, pad_id=pad_token_id,
-                                       sequence_bias=sequence_bias)
+                                       length_penalty=length_penalty, eos_id=one(default("eos_token_id", eos_token_id)),
+                                       pad_id=one(default("pad_token_id", pad_token_id)), sequence_bias=sequence_bias,
+                                       forced_decoder_ids=forced, begin_index=begin_index)
 
 
 def _resolve_device(device_map):
