@@ -22,6 +22,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # algorithmic work per training sample, fwd+bwd: whisper-base, L=32, LoRA r=32
 GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
+# encoder-only forward + backward (conv stem + 6 layers + adapters; SURVEY §8d: encoder forward 100.49 GFLOP, backward =
+# the whole backward 126.03 minus the decoder's dgrad 13.15): what north_star's ">= 40 % MFMA on whisper-base encoder
+# fwd+bwd" is measured on
+ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 
 
@@ -49,21 +53,102 @@ def cpu_baseline(dims, r, alpha):
             "sample": f"oracle fp32 fwd+bwd, whisper-base {dims.ch}-ch, B={B}, {n} timed passes after 1 warm-up"}
 
 
+def _kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ns_gemm_p8.hip", "ns_gemm_epi.h"):
+        h.update(open(os.path.join(ROOT, "neuspeech1_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    need separate profiler runs, so they cannot be collected inside this process): profiles/r1_f_pmc_traffic.json."""
+    need separate profiler runs, so they cannot be collected inside this process): profiles/r2_pmc_traffic.json, written
+    by tools/profile.sh pmc + tools/pmc_summary.py.  The file records the sha256 of the kernel's source; a file measured
+    on a different kernel revision is refused (traffic: null) rather than reported."""
     try:
-        import json as _j
-        d = _j.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_f_pmc_traffic.json")))
-        return round(d["hbm_bytes_per_launch"]) if kernel and d.get("kernel") == kernel else None
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        if not kernel or d.get("kernel") != kernel or d.get("kernel_source_sha256_16") != _kernel_source_hash():
+            return None
+        return round(d["hbm_bytes_per_launch"])
     except Exception:
         return None
 
 
-def eval_tokens_per_s(train_eng, xd, ld, dev):
+def cpu_reference_object(dims, B=4):
+    """SURVEY §8(d)'s CPU leg as specified: the object evaluation.py:72-86 builds -- stock `transformers` Whisper (third
+    party, in the image; eager attention, fp32) with the build's own 3-line conv stack installed -- on the host cores.
+    Train: B=4, 1 warm-up + 3 timed forward+backward passes, trainables = the conv stem (the adapters' extra weight
+    gradients, ~6 % of the FLOPs, are absent: peft is not in the image).  Decode: B=4, 40 new tokens, greedy and beam-5 +
+    repetition penalty 5 + no-repeat-2 through GenerationMixin.generate (the reference's call shape,
+    evaluation.py:369-386)."""
+    import torch
+    import transformers
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from neuspeech1_amd.weights import make_state_dict, synth_batch
+    from utils.model_utils import projection_module
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = WhisperConfig(vocab_size=dims.vocab, num_mel_bins=80, d_model=dims.d, encoder_layers=dims.enc_layers,
+                        decoder_layers=dims.dec_layers, encoder_attention_heads=dims.heads,
+                        decoder_attention_heads=dims.heads, encoder_ffn_dim=dims.ffn, decoder_ffn_dim=dims.ffn,
+                        max_source_positions=dims.src_pos, max_target_positions=dims.tgt_pos, pad_token_id=dims.pad_id,
+                        bos_token_id=dims.bos_id, eos_token_id=dims.eos_id, decoder_start_token_id=dims.start_id,
+                        attn_implementation="eager", suppress_tokens=[], begin_suppress_tokens=[])
+    model = WhisperForConditionalGeneration(cfg)
+    model.model.encoder.set_input_embeddings(projection_module(config_name="base", meg_ch=dims.ch, d_model=dims.d))
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(dims, 42).items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    model.load_state_dict(sd, strict=False)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    for n_, p_ in model.named_parameters():
+        if n_.startswith("model.encoder.conv"):
+            p_.requires_grad_(True)
+    x, labels = synth_batch(dims, B, 1234)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(labels)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        model(input_features=xt, labels=lt).loss.backward()
+    model.train()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    train = B * 3 / (time.perf_counter() - t0)
+    model.eval()
+    out = {"kind": "reference-object", "cores": cores, "train_samples_per_s": round(train, 4), "unit_decode": "tokens/s",
+           "sample": f"stock transformers {transformers.__version__} Whisper (eager, fp32) + conv stack, whisper-base {dims.ch}-ch, "
+                     f"B={B}: 1+3 fwd+bwd passes; GenerationMixin.generate 40 new tokens"}
+    common = dict(do_sample=False, max_new_tokens=40, decoder_input_ids=lt[:, :4].clone(), suppress_tokens=[dims.eos_id],
+                  begin_suppress_tokens=None, pad_token_id=dims.pad_id, eos_token_id=dims.eos_id)
+    gen = transformers.GenerationMixin.generate
+    with torch.no_grad():
+        for name, kw in (("greedy", dict(num_beams=1)), ("beam5_rep5_ngram2", dict(num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2))):
+            t0 = time.perf_counter()
+            o = gen(model, xt, **kw, **common)
+            out[name] = round(B * (o.shape[1] - 4) / (time.perf_counter() - t0), 2)
+    return out
+
+
+def decode_bytes_per_step(dims, B, nb, t):
+    """algorithmic HBM bytes of ONE decode step at sequence position t: the decoder's fp16 weights once
+    (per layer: self q|k|v + out, cross q + out, fc1, fc2; plus the tied LM head), the cross-attention K and V of every
+    SEQUENCE once (shared by its beams), the self-attention K/V cache of every beam row up to t."""
+    d, f, nl = dims.d, dims.ffn, dims.dec_layers
+    w = nl * (4 * d * d + 2 * d * d + 2 * d * f) * 2 + dims.vocab * d * 2
+    cross = B * nl * 2 * dims.src_pos * d * 2
+    self_kv = B * nb * nl * 2 * t * d * 2
+    return w + cross + self_kv
+
+
+def eval_tokens_per_s(dev):
     """BASELINE's second metric (eval tokens/sec): whisper-base, 273-ch, B = 128, 64 new tokens with
     EOS suppressed so every row does identical work; tokens/s = emitted tokens (prompt excluded) / wall time including
-    the encoder pass.  Reported beside the headline metric, never as `value`."""
+    the encoder pass.  Reported beside the headline metric, never as `value`.  `roofline` = the HBM roofline of the
+    decode STEP: algorithmic bytes per step / measured time per step (difference of a 64- and a 32-token run, so the
+    encoder pass and the prompt cancel), against the 8 TB/s spec and the 6.3 TB/s achievable rate."""
     import torch
     from neuspeech1_amd.engine import MegWhisperEngine
     from neuspeech1_amd.generate import Generator
@@ -75,15 +160,31 @@ def eval_tokens_per_s(train_eng, xd, ld, dev):
     x, labels = synth_batch(dims, B, 1234)
     x = torch.from_numpy(x).to(dev)
     prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
-    out = {"workload": "whisper-base 273-ch, B=128, prompt 4, 64 new tokens, EOS suppressed, encoder pass included", "unit": "tokens/s"}
-    for name, nb, kw in (("greedy", 1, {}), ("beam5_rep5_ngram2", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
-        for it in range(2):
+    out = {"workload": "whisper-base 273-ch, B=128, prompt 4, 64 new tokens, EOS suppressed, encoder pass included", "unit": "tokens/s",
+           "roofline": {}}
+
+    def run(nb, kw, new):
+        best = None
+        for _ in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            o = gen.generate(x, prompt, num_beams=nb, max_new_tokens=NEW, suppress_tokens=[dims.eos_id], check_every=8, **kw)
+            o = gen.generate(x, prompt, num_beams=nb, max_new_tokens=new, suppress_tokens=[dims.eos_id], check_every=8, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        out[name] = round(B * (o.shape[1] - 4) / dt, 1)
+            best = dt if best is None else min(best, dt)
+        return best, o.shape[1] - 4
+
+    for name, nb, kw in (("greedy", 1, {}), ("beam5_rep5_ngram2", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
+        t64, n64 = run(nb, kw, NEW)
+        t32, n32 = run(nb, kw, NEW // 2)
+        out[name] = round(B * n64 / t64, 1)
+        ms_step = (t64 - t32) / max(n64 - n32, 1) * 1e3
+        t_mid = 4 + (n32 + n64) // 2                       # mean cache length over the differenced steps
+        by = decode_bytes_per_step(dims, B, nb, t_mid)
+        ach = by / (ms_step * 1e-3) / 1e9
+        out["roofline"][name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                                 "frac_of_achievable_6300": round(ach / 6300.0, 4), "ms_per_step": round(ms_step, 4),
+                                 "algorithmic_bytes_per_step": by}
     return out
 
 
@@ -192,13 +293,40 @@ def main():
                 "gflop_per_launch": round(fl / n / 1e9, 2),
                 "step_share": {k: {"ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 1),
                                    "launches": v[2]} for k, v in tot.items()}}
-    cpu = None
+    # encoder-only forward + backward (the quantity north_star's 40 % MFMA target is stated on): HIP events on the
+    # launch stream at the encoder's section boundaries, one extra local step on rank 0
+    enc = None
+    if rank == 0 and not args.no_roofline:
+        eng.section_events = {}
+        eng.train_step(xd, ld)
+        torch.cuda.synchronize()
+        ev_, eng.section_events = eng.section_events, None
+        fwd_ms = ev_["enc_fwd_begin"].elapsed_time(ev_["enc_fwd_end"])
+        bwd_ms = ev_["enc_bwd_begin"].elapsed_time(ev_["enc_bwd_end"])
+        gfe = ENC_GFLOP_PER_SAMPLE.get(args.ch, ENC_GFLOP_PER_SAMPLE[208])
+        enc = {"fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "algorithmic_gflop_per_sample": gfe,
+               "mfma_frac": round(B * gfe * 1e9 / ((fwd_ms + bwd_ms) * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+
+    dp = None
+    if red is not None:
+        torch.cuda.synchronize()
+        ms_, by_ = red.exposed_ms(last=args.steps)
+        dp = {"allreduce_bytes_per_step": by_, "exposed_allreduce_ms_per_step": round(ms_, 4), "chunks": 3,
+              "backend": os.environ.get("NS_DIST_BACKEND", "nccl")}
+
+    cpu = cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(dims, args.lora_r, 2.0 * args.lora_r)
+        try:
+            cpu_ref = cpu_reference_object(dims)
+        except Exception as e:      # a reported baseline, not the product: never fail the bench line over it
+            cpu_ref = {"kind": "reference-object", "error": repr(e)[:200]}
 
     ev = None
     if rank == 0 and world == 1 and not args.no_eval:
-        ev = eval_tokens_per_s(eng, xd, ld, dev)
+        del eng
+        torch.cuda.empty_cache()
+        ev = eval_tokens_per_s(dev)
 
     if world > 1:
         dist.barrier()
@@ -215,8 +343,10 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_sample": gf,
                        "whole_step_mfma_frac": round(value / world * gf * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                       "encoder_fwd_bwd_mfma_frac": enc["mfma_frac"] if enc else None,
                        "final_loss": round(loss_v, 4)},
-            "roofline": roof, "cpu_baseline": cpu, "eval": ev,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_reference_object": cpu_ref, "encoder_fwd_bwd": enc,
+            "dp": dp, "eval": ev,
         }
         print(json.dumps(out), flush=True)
 

@@ -21,6 +21,7 @@
 //   TN: fp32 atomics straight from the accumulator layout (lanes 0-31 = 128
 //       contiguous bytes of one row: the full-rate atomic shape).
 #include "ns_gemm_epi.h"
+#include <mutex>
 
 namespace {
 
@@ -341,11 +342,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
 
 template <bool TN, int BN, bool DROP>
 void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute((const void*)ns_gemm_kernel<TN, BN, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL((ns_gemm_kernel<TN, BN, DROP>), grid, dim3(NTHREADS), lds, st, *d);
 }
 

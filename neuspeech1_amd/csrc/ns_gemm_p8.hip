@@ -23,6 +23,7 @@
 // columns of one output row: the fp32 tile goes to LDS with ds_write_b128 (row stride 260 floats) in two 128-row
 // halves, and the shared vector epilogue streams it out.
 #include "ns_gemm_epi.h"
+#include <mutex>
 
 namespace {
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
         for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // DMA sources.  Wave w fills region rows [16w, 16w+16) as two 1-KiB pieces (8 rows x 128 B, lane-linear).
-  uint32_t a_src[2][2], b_src[2][2], a2_src[2][2] = {{0, 0}, {0, 0}}, b2_src[2][2] = {{0, 0}, {0, 0}};
+  uint32_t a_src[2][2], b_src[2][2];
   int my_chunk[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -110,39 +111,28 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
       const int brow = ((rr >> 5) << 6) + h * 32 + (rr & 31);
       a_src[h][j] = (uint32_t)(ns_rm_off64(p.am, min(m0 + arow, p.M - 1)) + my_chunk[j] * 8);
       b_src[h][j] = (uint32_t)((long long)min(n0 + brow, p.N - 1) * p.bm.ld + my_chunk[j] * 8);
-      if (p.K2 > 0) {
-        const int goff = p.a2_ngroup > 0 ? (n0 / p.a2_ngroup) * p.K2 : 0;
-        a2_src[h][j] = (uint32_t)(ns_rm_off64(p.am2, min(m0 + arow, p.M - 1)) + goff + my_chunk[j] * 8);
-        b2_src[h][j] = (uint32_t)((long long)min(n0 + brow, p.N - 1) * p.ldb2 + my_chunk[j] * 8);
-      }
     }
   }
 
-  const int steps1 = (p.K + BK - 1) / BK;
-  const int steps2 = (p.K2 + BK - 1) / BK;
-  const bool seg2_first = DROP && steps2 > 0;
-  // with dropout the (A2, B2) product runs FIRST and is masked before the main product accumulates on top; its tile
-  // count is padded to even so that the mask falls between two passes of the (two-tile) loop body instead of sitting
-  // inside it (1.5 k instructions of mask code in the loop body cost 20-90 us per GEMM in instruction fetch alone)
-  const int steps2p = seg2_first ? (steps2 + 1) & ~1 : steps2;
-  const int nsteps = steps1 + steps2p;
+  // The (A2, B2) product (the LoRA up-projection: K2 = r or 3r, i.e. 16 .. 96) does NOT go through the LDS ring: a
+  // 64-deep ring tile for a 32-deep operand cost a whole K tile of operand delivery (+30 % on the q|k|v shape, two
+  // padded tiles on the dropout variant).  Its fragments are loaded from global memory (L2 / Infinity Cache: u was just
+  // written) straight into MFMA operand registers and multiplied while the prologue's LDS-DMA pieces are in flight.
+  const int nsteps = (p.K + BK - 1) / BK;
 
   auto stage = [&](int tt, int region, int buf) __attribute__((always_inline)) {
-    bool is2; int k0;
-    if (seg2_first) { is2 = tt < steps2p; k0 = (is2 ? tt : tt - steps2p) * BK; }
-    else { is2 = tt >= steps1; k0 = (is2 ? tt - steps1 : tt) * BK; }
-    int klen = (is2 ? p.K2 : p.K) - k0;     // <= 0 past the segment's end (padding tiles): fetched as zeros
-    if (tt >= nsteps) klen = 0;
+    const int k0 = tt * BK;
+    int klen = p.K - k0;                    // <= 0 past the end (padding tiles): fetched as zeros
 #ifdef NS_P8_STAMPS
     if (p.flags & (1 << 30)) return;   // diagnostic build: no loads
 #endif
     const int h = region & 1;
     const bool isb = region >= 2;
     char* const dst = smem + buf * BUF + region * REGION + wave * 2048;
-    const half_t* const base = (const half_t*)(isb ? (is2 ? p.B2 : p.B) : (is2 ? p.A2 : p.A));
+    const half_t* const base = (const half_t*)(isb ? p.B : p.A);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const uint32_t off = isb ? (is2 ? b2_src[h][j] : b_src[h][j]) : (is2 ? a2_src[h][j] : a_src[h][j]);
+      const uint32_t off = isb ? b_src[h][j] : a_src[h][j];
       const bool ok = my_chunk[j] * 8 < klen;
       glds16(ok ? base + (size_t)off + k0 : (const half_t*)ns_p8_zero_chunk, dst + j * 1024);
     }
@@ -219,10 +209,114 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     NS_P8_RUN(1, 0);
   };
 
+  // second product, round 0: the fragment loads go out FIRST (12 global_load_dwordx4 per lane), the 12 prologue DMA
+  // pieces behind them; vmcnt(12) then says "fragments landed" without waiting for a single DMA piece.  The loads are
+  // inline asm (hipcc would wait vmcnt(0) for an ordinary load while LDS-DMA is in flight, draining the prologue).
+  half8 a2f[2][4], b2f[2][2];
+  const half_t* a2p[2][4];
+  const half_t* b2p[2][2];
+  const bool k2ok = p.K2 > 0 && 8 * lg < p.K2;
+  if (p.K2 > 0) {
+    // a 64-column wave strip lies inside ONE column group (a2_ngroup % 64 == 0)
+    const int goff = p.a2_ngroup > 0 ? ((n0 + wn * 64) / p.a2_ngroup) * p.K2 : 0;
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int row = min(m0 + wm * 128 + ah * 64 + mt * 16 + l15, p.M - 1);
+        a2p[ah][mt] = (const half_t*)p.A2 + ns_rm_off64(p.am2, row) + goff + (k2ok ? 8 * lg : 0);
+      }
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = min(n0 + wn * 64 + bh * 32 + nt * 16 + l15, p.N - 1);
+        b2p[bh][nt] = (const half_t*)p.B2 + (long long)col * p.ldb2 + (k2ok ? 8 * lg : 0);
+      }
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a2f[ah][mt]) : "v"(a2p[ah][mt]) : "memory");
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b2f[bh][nt]) : "v"(b2p[bh][nt]) : "memory");
+  }
   // prologue: tile 0 complete + the first two regions of tile 1
   NS_STAMP(1);
   stage(0, RA0, 0); stage(0, RB0, 0); stage(0, RB1, 0); stage(0, RA1, 0);
   stage(1, RA0, 1); stage(1, RB0, 1);
+  if (p.K2 > 0) {
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mma2 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[ah][mt][bh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2f[bh][nt], a2f[ah][mt], acc[ah][mt][bh][nt], 0, 0, 0);
+    };
+    // round 0: everything issued after the 12 fragment loads is the 12 DMA pieces
+    asm volatile("s_waitcnt vmcnt(12)"
+                 : "+v"(a2f[0][0]), "+v"(a2f[0][1]), "+v"(a2f[0][2]), "+v"(a2f[0][3]), "+v"(a2f[1][0]), "+v"(a2f[1][1]),
+                   "+v"(a2f[1][2]), "+v"(a2f[1][3]), "+v"(b2f[0][0]), "+v"(b2f[0][1]), "+v"(b2f[1][0]), "+v"(b2f[1][1])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!k2ok) {      // lanes whose 8 k-values lie past K2 (K2 = 16: lanes 32..63) contribute zeros
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a2f[ah][mt] = hz;
+    }
+    mma2();
+    // further rounds (K2 > 32: the stacked q|k|v bottleneck of a dgrad, 3r): loaded behind the DMA pieces, so their
+    // wait also covers the prologue (which phase 1 needs anyway)
+    for (int k0 = 32; k0 < p.K2; k0 += 32) {
+      const bool ok = k0 + 8 * lg < p.K2;
+      const int ko = ok ? k0 : 0;
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a2f[ah][mt]) : "v"(a2p[ah][mt] + ko) : "memory");
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b2f[bh][nt]) : "v"(b2p[bh][nt] + ko) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(a2f[0][0]), "+v"(a2f[0][1]), "+v"(a2f[0][2]), "+v"(a2f[0][3]), "+v"(a2f[1][0]), "+v"(a2f[1][1]),
+                     "+v"(a2f[1][2]), "+v"(a2f[1][3]), "+v"(b2f[0][0]), "+v"(b2f[0][1]), "+v"(b2f[1][0]), "+v"(b2f[1][1])
+                   :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!ok) {
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a2f[ah][mt] = hz;
+      }
+      mma2();
+    }
+    if (DROP) {
+      // LoRA-dropout mask on the (A2, B2) product, before the main product accumulates on top
+      const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
+              const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
+              const uint32_t w = ns_drop_word(p.drop_seed, row, col >> 2);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] : 0.f;
+            }
+    }
+  }
   // only RA0 / RB0 of tile 0 (the first four pieces) must have landed: phase 1 reads nothing else, and the in-loop
   // vmcnt(8) of phases 1 and 2 retires RB1 / RA1 one phase before they are read
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -230,28 +324,6 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
   NS_STAMP(2);
   if (wm == 1) NS_P8_BARRIER();     // group 1 runs one barrier interval behind group 0
   int t = 0;
-  if (DROP && seg2_first) {
-    for (; t < steps2p; t += 2) {
-      tile(t, 0);
-      tile(t + 1, 1);
-    }
-    // LoRA-dropout mask on the (A2, B2) product (the DMA pieces of the next tiles stay in flight meanwhile)
-      const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
-            const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
-            const uint32_t w = ns_drop_word(p.drop_seed, row, col >> 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] : 0.f;
-          }
-  }
   for (; t < nsteps; t += 2) {
     tile(t, 0);
     tile(t + 1, 1);
@@ -391,12 +463,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute((const void*)ns_gemm_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)ns_gemm_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr = true;
-  }
+  });
   if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_p8_kernel<true>, dim3(tiles), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL(ns_gemm_p8_kernel<false>, dim3(tiles), dim3(NTH), LDS_BYTES, st, *d);
   return 0;

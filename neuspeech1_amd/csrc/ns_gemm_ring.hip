@@ -9,6 +9,7 @@
 // ds_read_b128 address (never on the LDS destination), which makes the fragment reads (lane = row,
 // same chunk) conflict-free across the 16-lane ds_read_b128 groups.
 #include "ns_gemm_epi.h"
+#include <mutex>
 
 namespace {
 
@@ -179,12 +180,11 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   const size_t lds = NST * STAGE_BYTES;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  });
   if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring_kernel<true>, dim3(tiles), dim3(NTH), lds, st, *d);
   else hipLaunchKernelGGL(ns_gemm_ring_kernel<false>, dim3(tiles), dim3(NTH), lds, st, *d);
   return 0;

@@ -10,6 +10,7 @@
 // wave between them).  Epilogue: the fp32 tile goes through LDS in four 64-row chunks (the ring is dead by then)
 // so all global accesses are row vectors (shared ns_nt_epilogue).
 #include "ns_gemm_epi.h"
+#include <mutex>
 
 namespace {
 
@@ -186,12 +187,11 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring256_kernel(const ns_gemm_d
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   const size_t lds = 2 * STAGE_BYTES;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute((const void*)ns_gemm_ring256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)ns_gemm_ring256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  });
   if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring256_kernel<true>, dim3(tiles), dim3(NTH), lds, st, *d);
   else hipLaunchKernelGGL(ns_gemm_ring256_kernel<false>, dim3(tiles), dim3(NTH), lds, st, *d);
   return 0;

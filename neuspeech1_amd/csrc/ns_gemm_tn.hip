@@ -7,6 +7,7 @@
 // Tiles: <128,128> (conv weight grads), <32,128> (LoRA dA: r x K), <128,32> (LoRA dB: N x r).  The reduction is split
 // over gridDim.z and accumulated with fp32 atomics in the full-rate shape (128 contiguous bytes per half wave).
 #include "ns_common.h"
+#include <mutex>
 
 namespace {
 
@@ -172,11 +173,10 @@ template <int BI, int BJ, bool DROP>
 void launch_tn(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BI - 1) / BI) * ((d->N + BJ - 1) / BJ);
   const size_t lds = 2 * (size_t)BKM * (RowStride<BI>::bytes + RowStride<BJ>::bytes);
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute((const void*)ns_gemm_tn_kernel<BI, BJ, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL((ns_gemm_tn_kernel<BI, BJ, DROP>), dim3(tiles, 1, d->splits), dim3(NTH), lds, st, *d);
 }
 

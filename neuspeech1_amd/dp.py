@@ -26,12 +26,15 @@ class GradReducer:
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self.native_avg = backend == "nccl"   # RCCL implements ReduceOp.AVG; gloo does not
         self.chunks = []
+        self.bytes_per_step = 0
+        self._waits = []          # (event before, event after) the optimizer stream's wait for the side stream, per step
 
     def on_ready(self, lo: int, hi: int):
         """G[lo:hi] is final on the current stream: start its all-reduce on the side stream."""
         if (self.world == 1 and not self.force) or hi <= lo:
             return
         self.chunks.append((lo, hi))
+        self.bytes_per_step += 4 * (hi - lo)
         view = self.G[lo:hi]
         if self.cuda:
             ev = torch.cuda.Event()
@@ -52,5 +55,23 @@ class GradReducer:
     def finish(self):
         """Make the optimizer (current stream) wait for every chunk."""
         if self.cuda and (self.world > 1 or self.force):
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur = torch.cuda.current_stream()
+            if len(self._waits) < 4096:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.side)
+                e1.record(cur)
+                self._waits.append((e0, e1, self.bytes_per_step))
+            else:
+                cur.wait_stream(self.side)
         self.chunks.clear()
+        self.bytes_per_step = 0
+
+    def exposed_ms(self, last: int | None = None):
+        """Per step: how long the optimizer's stream sat waiting for the all-reduce stream AFTER backward had finished,
+        i.e. the collective time that backward did not hide (call after a device synchronize).  Returns (mean exposed ms
+        over the `last` recorded steps, bytes reduced per step)."""
+        w = self._waits[-last:] if last else self._waits
+        if not w:
+            return 0.0, 0
+        return sum(e0.elapsed_time(e1) for e0, e1, _ in w) / len(w), w[-1][2]

@@ -553,8 +553,18 @@ class MegWhisperEngine:
                  drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
 
     # ------------------------------------------------------------------ forward
+    def _mark(self, name):
+        """bench.py's section timing (encoder-only forward / backward): HIP events on the launch stream, only when
+        `section_events` is a dict"""
+        ev = getattr(self, "section_events", None)
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            ev[name] = e
+
     def encode(self, x32: torch.Tensor, b: dict, train: bool):
         """MEG signal (B, ch, T) fp32 -> encoder states enc16 (B*S, d) fp16."""
+        self._mark("enc_fwd_begin")
         dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
         B, T, S, Cp = b["B"], dims.T, dims.src_pos, dims.ch_pad
         M = B * S
@@ -635,6 +645,7 @@ class MegWhisperEngine:
         hlast = h[2 * dims.enc_layers] if train else h[0]
         b["h_last"] = hlast
         ops.layernorm_fwd(hlast, *self.enc_ln, b["enc16"], *b["enc_st"], M, d)
+        self._mark("enc_fwd_end")
         return b["enc16"]
 
     def _layer_seed(self, i):
@@ -779,6 +790,7 @@ class MegWhisperEngine:
             dgrad("qkv", dq, ML, b["xs"][i], 0, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h0, *b["st_s"][i], Lw["ln1"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
         # ---- encoder
+        self._mark("enc_bwd_begin")
         h = b["h"]
         ops.layernorm_bwd(b["denc32"], True, h[2 * dims.enc_layers], *b["enc_st"], self.enc_ln[0], None, b["dh32"],
                           b["dh16"], M, d)
@@ -852,6 +864,7 @@ class MegWhisperEngine:
         # ---- conv stem (all three convs are trainable: modules_to_save, finetune.py:202)
         if self.train_convs:
             self._stem_backward(b)
+        self._mark("enc_bwd_end")
         if on_ready is not None:
             on_ready(self.lora_end, self.n_train)
 

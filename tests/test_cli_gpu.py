@@ -463,3 +463,8 @@ def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
     assert d["roofline"]["kernel"] and d["cpu_baseline"] is None and d["vs_baseline"] is None
+    # the first real multi-GPU run must yield a diagnosis, not just a number: bytes reduced per step and the part of the
+    # all-reduce that backward did not hide (the optimizer stream's wait for the side stream)
+    assert d["dp"]["allreduce_bytes_per_step"] > 1e6 and d["dp"]["exposed_allreduce_ms_per_step"] >= 0.0
+    assert d["dp"]["exposed_allreduce_ms_per_step"] < d["ms_per_step"]
+    assert 0.0 < d["config"]["encoder_fwd_bwd_mfma_frac"] < 1.0

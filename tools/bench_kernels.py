@@ -51,6 +51,14 @@ timeit("gemm qkv 96000x1536x512", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=Wqk
 timeit("gemm qkv+lora", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=Wqkv, ldb=d, M=M, N=3 * d, bias=bqkv, C16=qkv,
                                          c16m=rowmap(3 * d), A2=u3, am2=rowmap(3 * r), K2=r, B2=sB3, ldb2=r, a2_ngroup=d),
        2.0 * M * 3 * d * (d + r))
+duq, AqT = rnd(M, 3 * r), rnd(d, 3 * r, scale=0.1)
+dx = torch.empty(M, d, device=dev, dtype=F16)
+WqkvT = rnd(d, 3 * d, scale=0.04)
+timeit("dgrad qkv 96000x512x1536", lambda: ops.gemm(A=qkv, am=rowmap(3 * d), K=3 * d, B=WqkvT, ldb=3 * d, M=M, N=d, C16=dx, c16m=rowmap(d)),
+       2.0 * M * 3 * d * d)
+timeit("dgrad qkv+lora(96)+drop", lambda: ops.gemm(A=qkv, am=rowmap(3 * d), K=3 * d, B=WqkvT, ldb=3 * d, M=M, N=d, C16=dx, c16m=rowmap(d),
+                                                   A2=duq, am2=rowmap(3 * r), K2=3 * r, B2=AqT, ldb2=3 * r, drop_p=0.05, drop_seed=5),
+       2.0 * M * (3 * d + 3 * r) * d)
 Wo, bo = rnd(d, d, scale=0.04), rnd(d, dtype=F32)
 h32 = rnd(M, d, dtype=F32)
 h32o = torch.empty_like(h32)
@@ -61,6 +69,21 @@ pre, gf = torch.empty(M, f, device=dev, dtype=F16), torch.empty(M, f, device=dev
 timeit("gemm fc1+gelu 96000x2048x512", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, bias=b1, C16=pre,
                                                          c16m=rowmap(f), G16=gf, g16m=rowmap(f), flags=ops.NS_GEMM_GELU),
        2.0 * M * d * f)
+timeit("gemm fc1 plain (C16 only)", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, bias=b1, C16=pre, c16m=rowmap(f)),
+       2.0 * M * d * f)
+timeit("gemm fc1 gelu (G16 only)", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, bias=b1, G16=gf, g16m=rowmap(f),
+                                                    flags=ops.NS_GEMM_GELU), 2.0 * M * d * f)
+timeit("gemm fc1 gelu+savegrad+lora", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, bias=b1, C16=pre, c16m=rowmap(f),
+                                                       G16=gf, g16m=rowmap(f), flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD,
+                                                       A2=u3, am2=rowmap(3 * r), K2=r, B2=rnd(f, r, scale=0.1), ldb2=r),
+       2.0 * M * (d + r) * f)
+W1T = rnd(d, f, scale=0.02)
+du1, A1T = rnd(M, r), rnd(f, r, scale=0.1)
+timeit("dgrad fc2 mulp 96000x2048x512", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, C16=gf, c16m=rowmap(f),
+                                                         P16=pre, p16m=rowmap(f), flags=ops.NS_GEMM_MUL_P16), 2.0 * M * d * f)
+timeit("dgrad fc2 mulp+lora+drop", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=W1, ldb=d, M=M, N=f, C16=gf, c16m=rowmap(f),
+                                                    P16=pre, p16m=rowmap(f), flags=ops.NS_GEMM_MUL_P16, A2=du1, am2=rowmap(r), K2=r,
+                                                    B2=A1T, ldb2=r, drop_p=0.05, drop_seed=5), 2.0 * M * (d + r) * f)
 W2 = rnd(d, f, scale=0.02)
 timeit("gemm fc2+res 96000x512x2048", lambda: ops.gemm(A=gf, am=rowmap(f), K=f, B=W2, ldb=f, M=M, N=d, bias=bo, R32=h32,
                                                         H32=h32o, h32m=rowmap(d)), 2.0 * M * d * f)

@@ -240,11 +240,20 @@ def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630), sequence_bia
                   return_dict_in_generate=True, output_scores=True)
     gen = transformers.GenerationMixin.generate
     with torch.no_grad():
+        def margins(o):
+            """per generated position: processed top-1 minus top-2 score of the reference's own decision (fp32).  A greedy
+            decision whose margin is below fp16 resolution cannot be required of an fp16 path (tests: ids must match up
+            to the first position whose margin is < 0.03; everything after such a flip is a different sequence)."""
+            t2 = [torch.topk(sc, 2, dim=-1).values for sc in o.scores]
+            return torch.stack([(v[:, 0] - v[:, 1]) for v in t2], 1).numpy().astype(np.float32)
+
         o = gen(model, feats, num_beams=1, **common)
         g["greedy"] = o.sequences.numpy()
+        g["greedy_margin"] = margins(o)
         g["greedy_step0_scores"] = o.scores[0].numpy()[:, :64].astype(np.float32)
         o = gen(model, feats, num_beams=1, repetition_penalty=5.0, no_repeat_ngram_size=2, **common)
         g["greedy_rp"] = o.sequences.numpy()
+        g["greedy_rp_margin"] = margins(o)
         o = gen(model, feats, num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2, **common)
         g["beam5_rp"] = o.sequences.numpy()
         g["beam5_rp_scores"] = o.sequences_scores.numpy().astype(np.float32)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/ (run ON the GPU box through gpurun):
+#   bash tools/profile.sh stats <tag> [bench args]   kernel-trace + stats of bench.py            -> gpurun_out/prof_<tag>/
+#   bash tools/profile.sh pmc   <tag>                 FETCH_SIZE / WRITE_SIZE in SEPARATE passes  -> gpurun_out/pmc_<tag>_*/
+#   bash tools/profile.sh decode <tag>                kernel stats of tools/bench_decode.py
+# Counters are collected in runs of their own (never together with --stats / trace domains other than kernel-trace).
+set -u
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
+mode="$1"; tag="$2"; shift 2
+cd /tmp && export TMPDIR=/tmp
+case "$mode" in
+  stats)
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_$tag.json" 2> "$OUT/prof_$tag.log"
+    ;;
+  pmc)
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_$c.json" 2> "$OUT/pmc_${tag}_$c.log"
+    done
+    python3 "$ROOT/tools/pmc_summary.py" "$tag"
+    ;;
+  decode)
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/tools/bench_decode.py" "$@" > "$OUT/decode_$tag.log" 2> "$OUT/prof_$tag.log"
+    ;;
+esac
