@@ -210,6 +210,26 @@ int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, c
                 float* reg_out_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * LoRA backward, the two products that read dy, in one pass over it (peft lora.Linear backward of
+ * y += scale * B (A drop(x)), finetune.py:187-212): for each of the G column groups of dy (q | k | v: G = 3, else 1)
+ *   du[:, g*r : (g+1)*r]  = alpha_du * dy_g sB_g           (M x r fp16; sBT[g] = (scale * B_g)^T, r x N fp16, ld = N)
+ *   dB[g] (N x lddb fp32) += alpha_db[g] * dy_g^T u_g       (fp32 atomics; u = the forward bottleneck, M x G*r fp16)
+ * dy_g = columns [g*N, (g+1)*N) of dy.  N % 256 == 0, r in {16, 32} (the padded rank), G in {1, 3};
+ * ns_lora_bwd_supported() says whether a shape is built (callers keep the two-GEMM path otherwise).
+ * `splits` = workgroups (row ranges), 0 = default.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const void* dy; const void* u; void* du;
+  const void* sBT[3]; float* dB[3];
+  int32_t M, N, r, G;
+  int32_t ldy, ldu, lddu, lddb;
+  float alpha_du; float alpha_db[3];
+  int32_t splits;
+} ns_lora_bwd_desc;
+int ns_lora_bwd_supported(int N, int r, int G);
+int ns_lora_bwd_dudb(const ns_lora_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused attention, head_dim 64.  Row (b*L + i) of each token-major matrix,
  * head h at column h*64.  q must be pre-scaled by head_dim^-0.5 (HF folds it
  * into q_proj's output, modeling_whisper.py:309).  causal: key j is visible to

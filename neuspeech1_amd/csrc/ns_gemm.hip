@@ -388,6 +388,12 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                    d->a2_ngroup, (d->N + d->a2_ngroup - 1) / d->a2_ngroup, d->K2);
     }
     NS_CHECK_ARG(!(d->flags & NS_GEMM_ATOMIC32), "ns_gemm(NT): ATOMIC32 is a TN-only epilogue");
+    if (d->splits > 1) {
+      // split-K NT: fp32 atomics into a caller-zeroed C32, nothing else (the LM-head dgrad: K = padded vocabulary)
+      NS_CHECK_ARG(d->C32 && !d->C16 && !d->G16 && !d->H32 && d->K2 == 0 && d->flags == 0 && d->drop_p == 0.f,
+                   "ns_gemm(NT): splits > 1 needs a plain C32 output (no fp16 / residual outputs, flags, second product)");
+      NS_CHECK_ARG(d->splits <= 64 && d->K / d->splits >= 256, "ns_gemm(NT): splits=%d for K=%d", d->splits, d->K);
+    }
   } else {
     NS_CHECK_ARG(d->C32 && (d->flags & NS_GEMM_ATOMIC32 || d->splits <= 1), "ns_gemm(TN): needs C32 (+ATOMIC32 when split)");
     NS_CHECK_ARG(d->am.seg_rows == d->bm.seg_rows, "ns_gemm(TN): A and B must share seg_rows");
@@ -415,6 +421,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   } else if (tn) {
     dim3 grid(tiles, 1, d->splits);
     if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
+  } else if (!tn && d->splits > 1) {
+    ns_gemm_ring_launch(d, st);
   } else if (g_use_ring != 6 && g_use_ring != 0 && ns_gemm_smallm_ok(d)) {
     ns_gemm_smallm_launch(d, st);   // decode shapes: 32x32 tiles, K split over the four waves (mode 6 = off, for A/B runs)
   } else if (skinny) {

@@ -54,6 +54,16 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // split-K (gridDim.y > 1; plain fp32 output only): K = 51 968 of the LM-head dgrad has 22 output tiles -- one K range
+  // per workgroup row, partial tiles summed by fp32 atomics straight from the accumulators (a 32x32 accumulator register
+  // is two 128-B row segments per wave instruction: the full-rate atomic shape)
+  int kbeg = 0, Kloc = p.K;
+  if (gridDim.y > 1) {
+    const int per = ((p.K + (int)gridDim.y - 1) / (int)gridDim.y + BKS - 1) / BKS * BKS;
+    kbeg = blockIdx.y * per;
+    Kloc = max(0, min(p.K, kbeg + per) - kbeg);
+  }
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -74,8 +84,8 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     const int row = 16 * (wave * 2 + jj) + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
     my_chunk[jj] = chunk;
-    a_src[jj] = (const half_t*)p.A + ns_rm_off64(p.am, min(m0 + row, p.M - 1)) + chunk * 8;
-    b_src[jj] = (const half_t*)p.B + (long long)min(n0 + row, p.N - 1) * p.bm.ld + chunk * 8;
+    a_src[jj] = (const half_t*)p.A + ns_rm_off64(p.am, min(m0 + row, p.M - 1)) + chunk * 8 + kbeg;
+    b_src[jj] = (const half_t*)p.B + (long long)min(n0 + row, p.N - 1) * p.bm.ld + chunk * 8 + kbeg;
   }
   if (p.K2 > 0) {
     const int goff = p.a2_ngroup > 0 ? (n0 / p.a2_ngroup) * p.K2 : 0;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     }
   }
 
-  const int steps1 = (p.K + BKS - 1) / BKS;
+  const int steps1 = (Kloc + BKS - 1) / BKS;
   const int steps2 = (p.K2 + BKS - 1) / BKS;
   const int nsteps = steps1 + steps2;
   const bool seg2_first = DROP && steps2 > 0;   // dgrad with LoRA dropout: (A2,B2) first, mask, then the main product
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   auto step_info = [&](int s, bool& is2, int& k0, int& klen) __attribute__((always_inline)) {
     if (seg2_first) { is2 = s < steps2; k0 = (is2 ? s : s - steps2) * BKS; }
     else { is2 = s >= steps1; k0 = (is2 ? s - steps1 : s) * BKS; }
-    klen = (is2 ? p.K2 : p.K) - k0;
+    klen = (is2 ? p.K2 : Kloc) - k0;
     klen = klen > BKS ? BKS : klen;
   };
   auto issue = [&](int s) __attribute__((always_inline)) {
@@ -158,6 +168,23 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     }
   }
 
+  if (gridDim.y > 1) {
+    const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lr;
+        if (col >= p.N) continue;
+        const float bz = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < p.M) atomicAdd(p.C32 + (long long)row * p.ldc32 + col, acc[i][j][r] * alpha + bz);
+        }
+      }
+    return;
+  }
   // ---- epilogue through LDS (the ring is dead: no DMA outstanding, wait for the last readers)
   __syncthreads();
   float* const ct = (float*)smem;
@@ -185,7 +212,8 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
     hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring_kernel<true>, dim3(tiles), dim3(NTH), lds, st, *d);
-  else hipLaunchKernelGGL(ns_gemm_ring_kernel<false>, dim3(tiles), dim3(NTH), lds, st, *d);
+  const int splits = ((d->flags & NS_GEMM_TN) || d->splits < 1) ? 1 : d->splits;   // > 1 only for the plain-C32 form (ns_gemm checks)
+  if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring_kernel<true>, dim3(tiles, splits), dim3(NTH), lds, st, *d);
+  else hipLaunchKernelGGL(ns_gemm_ring_kernel<false>, dim3(tiles, splits), dim3(NTH), lds, st, *d);
   return 0;
 }

@@ -183,6 +183,7 @@ class MegWhisperEngine:
         self.dec_ln = (g(dd + "layer_norm.weight"), g(dd + "layer_norm.bias"))
         self._build_trainables(sd, lora_sd)
         self._bufs = {}
+        self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
@@ -378,6 +379,7 @@ class MegWhisperEngine:
             self._orth_table, self._n_orth = ops.make_orth_jobs(oj, self.dev)
             self.reg_dev = torch.zeros(1, device=self.dev)
             self._gbf = torch.zeros(max(d, f) * r, device=self.dev, dtype=F32)
+            self._gbf3 = torch.zeros(max(3 * d, f) * r, device=self.dev, dtype=F32)
         self.refresh_operands()
 
     def refresh_operands(self):
@@ -475,6 +477,7 @@ class MegWhisperEngine:
                 b["ddu"] = h16(ML, 3 * r)
                 b["ddu_kv"] = h16(M, 2 * r)
             b["ddh32"] = f32(ML, d)
+            b["ddx32"] = f32(ML, d)
             b["ddh16"] = h16(ML, d)
             b["ddx16"] = h16(ML, d)
             b["ddqkv"] = h16(ML, 3 * d)
@@ -749,9 +752,19 @@ class MegWhisperEngine:
         M, ML, Vp = B * S, B * L, dims.vocab_pad
         hd = b["hd"]
         # ---- LM head + final decoder LN
-        ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C16=b["ddx16"], c16m=rowmap(d))
-        ops.layernorm_bwd(b["ddx16"], False, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
-                          b["ddh16"], ML, d)
+        # K = the padded vocabulary (51 968) against 22 output tiles: split K over ~1000 workgroups, fp32 atomics into
+        # a zeroed buffer that the LayerNorm backward reads as its fp32 input
+        tiles = ((ML + 127) // 128) * ((d + 127) // 128)
+        splits = max(1, min(64, Vp // 2048, -(-1024 // tiles)))
+        if splits > 1:
+            b["ddx32"].zero_()
+            ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C32=b["ddx32"], ldc32=d, splits=splits)
+            ops.layernorm_bwd(b["ddx32"], True, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
+                              b["ddh16"], ML, d)
+        else:
+            ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C16=b["ddx16"], c16m=rowmap(d))
+            ops.layernorm_bwd(b["ddx16"], False, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
+                              b["ddh16"], ML, d)
         first_enc = True
         for i in reversed(range(dims.dec_layers)):
             Lw = self.dec[i]
@@ -808,16 +821,13 @@ class MegWhisperEngine:
             if r:
                 # fc2: du = dy*sB / keep ; dB = s*dy^T u ; dA = du^T mask(gf) ; dgf = dy*W + mask * (du*A)
                 # (the kernels apply the dropout MASK only: 1/keep rides in du's alpha, forward in u's alpha)
-                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["fc2_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
-                self._cur_seed_save = self._cur_seed
-                self._wgrad_b(dy, d, b["u2"][i], r, M, d, p + "fc2", sc)
+                self._lora_du_db(dy, d, d, M, b["u2"][i], b["du"], [lo["fc2_sBT"]], [p + "fc2"], [sc])
                 self._with_seed(seed + 3, lambda: self._wgrad(b["du"], r, b["gf"][i], f, M, r, f, p + "fc2.lora_A", drop=True))
                 self._with_seed(seed + 3, lambda: self._dgrad(dy, M, Lw["fc2"], b["dpre_f"], P16=b["pre_f"][i], A2=b["du"],
                                                                lda2=r, K2=r, B2=lo["fc2_AT"], drop=True))
                 # fc1
                 dpf = b["dpre_f"]
-                ops.gemm(A=dpf, am=rowmap(f), K=f, B=lo["fc1_sBT"], ldb=f, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
-                self._wgrad_b(dpf, f, b["u1"][i], r, M, f, p + "fc1", sc)
+                self._lora_du_db(dpf, f, f, M, b["u1"][i], b["du"], [lo["fc1_sBT"]], [p + "fc1"], [sc])
                 self._with_seed(seed + 2, lambda: self._wgrad(b["du"], r, b["x2"][i], d, M, r, d, p + "fc1.lora_A", drop=True))
                 self._with_seed(seed + 2, lambda: self._dgrad(dpf, M, Lw["fc1"], b["dx16"], A2=b["du"], lda2=r, K2=r,
                                                                B2=lo["fc1_AT"], drop=True))
@@ -827,8 +837,7 @@ class MegWhisperEngine:
             ops.layernorm_bwd(b["dx16"], False, hmid, *b["st2"][i], Lw["ln2"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
             dy = b["dh16"]
             if r:
-                ops.gemm(A=dy, am=rowmap(d), K=d, B=lo["out_sBT"], ldb=d, M=M, N=r, C16=b["du"], c16m=rowmap(r), alpha=self._drop_inv())
-                self._wgrad_b(dy, d, b["uo"][i], r, M, d, p + "self_attn.out_proj", sc)
+                self._lora_du_db(dy, d, d, M, b["uo"][i], b["du"], [lo["out_sBT"]], [p + "self_attn.out_proj"], [sc])
                 self._with_seed(seed + 1, lambda: self._wgrad(b["du"], r, b["ao"][i], d, M, r, d,
                                                                p + "self_attn.out_proj.lora_A", drop=True))
                 self._with_seed(seed + 1, lambda: self._dgrad(dy, M, Lw["out"], b["dao"], A2=b["du"], lda2=r, K2=r,
@@ -840,11 +849,9 @@ class MegWhisperEngine:
                          ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][i], dO=b["dao"], dQ=dqkv, dK=(dqkv, d),
                          dV=(dqkv, 2 * d), Delta=b["delta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
             if r:
-                for j, (nm, key, a) in enumerate((("q_proj", "sBqT", sc * qs), ("k_proj", "sBkT", sc), ("v_proj", "sBvT", sc))):
-                    ops.gemm(A=(dqkv, j * d), am=rowmap(3 * d), K=d, B=lo[key], ldb=d, M=M, N=r, C16=(b["du3"], j * r),
-                             c16m=rowmap(3 * r), alpha=self._drop_inv())
-                    self._wgrad_b((dqkv, j * d), 3 * d, (b["uqkv"][i], j * r), 3 * r, M, d, p + f"self_attn.{nm}", a,
-                                  ename=p + "self_attn.qkv.lora_E", eoff=j * r)
+                self._lora_du_db(dqkv, 3 * d, d, M, b["uqkv"][i], b["du3"], [lo["sBqT"], lo["sBkT"], lo["sBvT"]],
+                                 [p + f"self_attn.{nm}" for nm in ("q_proj", "k_proj", "v_proj")], [sc * qs, sc, sc],
+                                 enames=[(p + "self_attn.qkv.lora_E", j * r) for j in range(3)])
                 self._with_seed(seed, lambda: self._wgrad(b["du3"], 3 * r, b["x1"][i], d, M, 3 * r, d,
                                                            p + "self_attn.qkv.lora_A", drop=True))
                 self._with_seed(seed, lambda: self._dgrad(dqkv, M, Lw["qkv"], b["dx16"], A2=b["du3"], lda2=3 * r, K2=3 * r,
@@ -882,6 +889,36 @@ class MegWhisperEngine:
         en = ename or key + ".lora_E"
         ops.adalora_fold_grads(tmp, self.pview(key + ".lora_B"), (self.pview(en), eoff), self.gview(key + ".lora_B"),
                                (self.gview(en), eoff), N, r, s)
+
+    def _lora_du_db(self, dy16, ldy, N, M, u16, du16, sBT, keys, alphas, enames=None):
+        """Backward of the adapter up-projections of ONE site (G = len(keys) column groups of dy: q | k | v, else one):
+        du_g = dy_g sB_g / keep and dB_g = s dy_g^T u_g.  One fused pass over dy (ns_lora_bwd_dudb) where the shape is
+        built, else the skinny GEMM + weight-gradient GEMM pair.  AdaLoRA: the product lands in a scratch buffer and
+        ns_adalora_fold_grads turns the gradient of the folded operand s*B*diag(E) into dB and dE."""
+        r, G = self.r, len(keys)
+        if ops.lora_bwd_supported(N, r, G) and not self.no_fused_lora_bwd:
+            if self.adalora:
+                tmp = self._gbf3[:G * N * r].view(G, N * r)
+                tmp.zero_()
+                dB = [tmp[g] for g in range(G)]
+                al = [1.0] * G
+            else:
+                dB = [self.gview(k + ".lora_B") for k in keys]
+                al = list(alphas)
+            ops.lora_bwd_dudb(dy=dy16, ldy=ldy, u=u16, ldu=G * r, du=du16, lddu=G * r, sBT=sBT, dB=dB, lddb=r, M=M, N=N, r=r,
+                              alpha_du=self._drop_inv(), alpha_db=al)
+            if self.adalora:
+                for g, k in enumerate(keys):
+                    en, eoff = enames[g] if enames else (k + ".lora_E", 0)
+                    ops.adalora_fold_grads(tmp[g], self.pview(k + ".lora_B"), (self.pview(en), eoff), self.gview(k + ".lora_B"),
+                                           (self.gview(en), eoff), N, r, alphas[g])
+            return
+        for g, k in enumerate(keys):
+            ops.gemm(A=(dy16, g * N) if G > 1 else dy16, am=rowmap(ldy), K=N, B=sBT[g], ldb=N, M=M, N=r,
+                     C16=(du16, g * r) if G > 1 else du16, c16m=rowmap(G * r), alpha=self._drop_inv())
+            en, eoff = enames[g] if enames else (None, 0)
+            self._wgrad_b((dy16, g * N) if G > 1 else dy16, ldy, (u16, g * r) if G > 1 else u16, G * r, M, N, k, alphas[g],
+                          ename=en, eoff=eoff)
 
     def _with_seed(self, seed, fn):
         save = self._cur_seed

@@ -118,6 +118,17 @@ class LogitsProcDesc(C.Structure):
     ]
 
 
+class LoraBwdDesc(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("u", C.c_void_p), ("du", C.c_void_p),
+        ("sBT", C.c_void_p * 3), ("dB", C.c_void_p * 3),
+        ("M", C.c_int32), ("N", C.c_int32), ("r", C.c_int32), ("G", C.c_int32),
+        ("ldy", C.c_int32), ("ldu", C.c_int32), ("lddu", C.c_int32), ("lddb", C.c_int32),
+        ("alpha_du", C.c_float), ("alpha_db", C.c_float * 3),
+        ("splits", C.c_int32),
+    ]
+
+
 class BeamDesc(C.Structure):
     _fields_ = [
         ("top_vals", C.c_void_p), ("top_idx", C.c_void_p),
@@ -155,6 +166,8 @@ SIGNATURES = {
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
+    "ns_lora_bwd_supported": (C.c_int, [_i, _i, _i]),
+    "ns_lora_bwd_dudb": (C.c_int, [C.POINTER(LoraBwdDesc), _vp]),
     "ns_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -279,3 +279,21 @@ def make_orth_jobs(jobs, device):
 def orth_reg(table, njobs, weight_over_num, loss_scale_dev, reg_out_dev):
     L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), _stream()),
             "ns_orth_reg")
+
+
+# ----------------------------------------------------------------------------- LoRA backward (du + dB in one pass over dy)
+def lora_bwd_supported(N: int, r: int, G: int) -> bool:
+    return bool(L.load().ns_lora_bwd_supported(N, r, G))
+
+
+def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du, alpha_db, splits=0):
+    """sBT / dB / alpha_db: one entry per column group of dy (q | k | v: three, else one)"""
+    d = L.LoraBwdDesc()
+    d.dy, d.u, d.du = ptr(dy), ptr(u), ptr(du)
+    G = len(sBT)
+    for g in range(G):
+        d.sBT[g], d.dB[g], d.alpha_db[g] = ptr(sBT[g]), ptr(dB[g]), alpha_db[g]
+    d.M, d.N, d.r, d.G = M, N, r, G
+    d.ldy, d.ldu, d.lddu, d.lddb = ldy, ldu, lddu, lddb
+    d.alpha_du, d.splits = alpha_du, splits
+    L.check(L.load().ns_lora_bwd_dudb(C.byref(d), _stream()), "ns_lora_bwd_dudb")

@@ -624,3 +624,39 @@ def test_dominant_gemm_at_bench_size_against_torch(ops, dev, name, N, K, kind):
                  flags=ops.NS_GEMM_MUL_P16)
         close(D[rows], (Ar @ B.float().T).half().float() * P[rows].float(), 8e-3, 3e-3, name)
         assert not torch.isnan(D.float()).any()
+
+
+@pytest.mark.parametrize("M,N,r,G,splits", [(1000, 512, 32, 1, 0), (520, 256, 16, 3, 3), (777, 2048, 32, 1, 5), (4096, 512, 32, 3, 0),
+                                            (333, 1280, 32, 1, 2), (64, 256, 32, 1, 0), (96000, 512, 32, 3, 0)])
+def test_lora_backward_du_and_dB_in_one_pass(ops, dev, M, N, r, G, splits):
+    """ns_lora_bwd_dudb (du_g = alpha dy_g sB_g and dB_g += alpha_g dy_g^T u_g from ONE pass over dy) against torch fp32,
+    ragged row counts, every built (N, G) shape class, the padded rank 16, accumulation into a non-zero dB, and the
+    bench size M = 96 000 (q | k | v)."""
+    assert ops.lora_bwd_supported(N, r, G) and not ops.lora_bwd_supported(N + 8, r, G) and not ops.lora_bwd_supported(N, 24, G)
+    dy = rnd((M, G * N), dev, 0.5, seed=1)
+    u = rnd((M, G * r), dev, 0.5, seed=2)
+    sBT = [rnd((r, N), dev, 0.1, seed=3 + g) for g in range(G)]
+    dB0 = [rnd((N, r), dev, 1.0, torch.float32, seed=10 + g) for g in range(G)]
+    dB = [t.clone() for t in dB0]
+    du = torch.full((M, G * r), float("nan"), device=dev, dtype=torch.float16)
+    al = [0.7, 1.3, 2.0][:G]
+    ops.lora_bwd_dudb(dy=dy, ldy=G * N, u=u, ldu=G * r, du=du, lddu=G * r, sBT=sBT, dB=dB, lddb=r, M=M, N=N, r=r, alpha_du=1.25,
+                      alpha_db=al, splits=splits)
+    for g in range(G):
+        dyg = dy[:, g * N:(g + 1) * N].float()
+        close(du[:, g * r:(g + 1) * r], 1.25 * dyg @ sBT[g].float().T, 2e-2 * (N / 512) ** 0.5, 4e-3, f"du group {g}")
+        ref = dB0[g] + al[g] * (dyg.T @ u[:, g * r:(g + 1) * r].float())
+        close(dB[g], ref, 2e-3 * max(1.0, (M / 1000) ** 0.5), 2e-3, f"dB group {g}")
+    assert not torch.isnan(du.float()).any()
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(300, 512, 51968, 12), (2816, 512, 51968, 12), (130, 200, 4096, 3)])
+def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
+    """split-K NT GEMM (the LM-head dgrad: K = the padded vocabulary against a handful of output tiles): fp32 atomics
+    into a zeroed C32, against torch fp32; ragged M / N, K ranges that do not divide evenly."""
+    A = rnd((M, K), dev, 0.05, seed=1)
+    B = rnd((N, K), dev, 0.05, seed=2)
+    C = torch.zeros(M, N, device=dev)
+    ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C32=C, ldc32=N, splits=splits)
+    ref = A.float() @ B.float().T
+    close(C, ref, 2e-3, 2e-3, "split-K NT")
