@@ -20,6 +20,9 @@ namespace {
 #ifndef NS_SM_DEPTH
 #define NS_SM_DEPTH 3      // 1 or 3 (ring of DEPTH + 1 stages, power of two)
 #endif
+#ifndef NS_SM_MAXM
+#define NS_SM_MAXM 1024
+#endif
 #ifndef NS_SM_MAXTILES
 #define NS_SM_MAXTILES 384
 #endif
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(SM_NT) void ns_gemm_smallm_kernel(const ns_gemm_des
 // Beyond ~384 tiles the 32 x 32 form is bound by operand traffic (every tile re-reads 32 rows of each operand at the
 // ~42 GB/s a CU can fetch): measured slower than the 128 x 32 LDS-staged tile there (tools/probe/smallm_ab.py).
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d) {
-  if ((d->flags & NS_GEMM_TN) || d->K2 != 0 || d->drop_p != 0.f || d->am.seg_rows != 0 || d->M > 1024 || d->N < 64 ||
+  if ((d->flags & NS_GEMM_TN) || d->K2 != 0 || d->drop_p != 0.f || d->am.seg_rows != 0 || d->M > NS_SM_MAXM || d->N < 64 ||
       d->N > 4096 || d->K < 256)
     return false;
   return ((d->M + 31) / 32) * ((d->N + 31) / 32) <= NS_SM_MAXTILES;

@@ -22,7 +22,10 @@ gen = Generator(eng, use_graph=os.environ.get("GRAPH", "1") == "1")
 x, labels = synth_batch(dims, B, 1234)
 x = torch.from_numpy(x).to(dev)
 prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
+ONLY = os.environ.get("BEAMS")     # "1" or "5": one mode only (clean rocprofv3 kernel stats per mode)
 for nb, kw in ((1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
+    if ONLY and int(ONLY) != nb:
+        continue
     for it in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

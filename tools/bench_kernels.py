@@ -154,3 +154,11 @@ for name, rows_ in (("colsum 64x6000x512", 64 * 6000), ("colsum 64x3002x512", 64
     a_ = rnd(rows_, 512)
     o_ = torch.zeros(512, device=dev)
     timeit(name, lambda: ops.colsum(a_, o_, rows_, 512, 512), 0.0, rows_ * 512 * 2)
+
+# decoder-side GEMMs of the training step (ML = 64 x 44 label positions)
+MLd = 64 * 44
+xdd = rnd(MLd, d)
+for name, n_, k_ in (("dec 2816x512x512", d, d), ("dec 2816x1536x512", 3 * d, d), ("dec 2816x2048x512", f, d), ("dec 2816x512x2048", d, f)):
+    a_, w_ = rnd(MLd, k_), rnd(n_, k_, scale=0.04)
+    o_ = torch.empty(MLd, n_, device=dev, dtype=F16)
+    timeit(name, lambda: ops.gemm(A=a_, am=rowmap(k_), K=k_, B=w_, ldb=k_, M=MLd, N=n_, C16=o_, c16m=rowmap(n_)), 2.0 * MLd * n_ * k_)
