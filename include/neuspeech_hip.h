@@ -60,7 +60,9 @@ enum {
   NS_GEMM_DROP_A = 16,   /* NT: A is multiplied by the LoRA-dropout keep mask (forward down-projection; mask only) */
   NS_GEMM_GELU_SAVE_GRAD = 32, /* with NS_GEMM_GELU: C16 = round16(gelu'(x)) instead of x = round16(acc+bias): the backward then
                                   multiplies (NS_GEMM_MUL_P16) instead of re-evaluating erf / exp per element */
-  NS_GEMM_MUL_P16 = 64   /* C16 = round16(round16(acc) * P16) */
+  NS_GEMM_MUL_P16 = 64,  /* C16 = round16(round16(acc) * P16) */
+  NS_GEMM_COLSUM_A = 128 /* TN: additionally H32[i] += alpha * sum_m A[m][i] (fp32 atomics; H32 = M floats): the bias gradient of
+                            a conv rides on its weight-gradient GEMM instead of a second pass over d(pre) */
 };
 
 /*

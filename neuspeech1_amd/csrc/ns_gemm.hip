@@ -355,6 +355,7 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
+bool ns_gemm_p8_fits(const ns_gemm_desc* d);
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
@@ -401,7 +402,12 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                  "ns_gemm(TN): M, N and row strides must be even");
     NS_CHECK_ARG(d->K2 == 0, "ns_gemm(TN): second product unsupported");
     NS_CHECK_ARG(d->splits >= 1 && d->splits <= 65535, "ns_gemm(TN): bad splits=%d", d->splits);
+    if (d->flags & NS_GEMM_COLSUM_A)
+      NS_CHECK_ARG(d->H32 && d->M > 96 && d->N > 96 && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 &&
+                       d->bm.ld % 8 == 0 && d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0,
+                   "ns_gemm(TN): COLSUM_A needs H32 and the 128 x 128 transposed-read kernel (M, N > 96, strides multiples of 8)");
   }
+  NS_CHECK_ARG(tn || !(d->flags & NS_GEMM_COLSUM_A), "ns_gemm: COLSUM_A is a TN-only side output");
   if (d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU / MUL_P16 need P16");
   NS_CHECK_ARG(!(d->flags & NS_GEMM_GELU_SAVE_GRAD) || (d->flags & NS_GEMM_GELU), "ns_gemm: GELU_SAVE_GRAD needs GELU");
   NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p <= 0.5f, "ns_gemm: drop_p out of range (0 .. 0.5)");
@@ -415,7 +421,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
   const size_t lds = 2 * TILE_BYTES + 2 * (size_t)bn * BK * 2;   // BN=128: 64 KiB (= the fp32 epilogue tile)
   hipStream_t st = (hipStream_t)stream;
-  if (tn && g_use_ring && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
+  if (tn && (g_use_ring || (d->flags & NS_GEMM_COLSUM_A)) && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
       d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 && d->M >= 8 && d->N >= 8) {
     ns_gemm_tn_launch(d, st);   // row-major staging + ds_read_b64_tr_b16 fragments
   } else if (tn) {
@@ -435,7 +441,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                      ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
     const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
-                       (!d->H32 || d->h32m.ld % 8 == 0);
+                       (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
     if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1)) ns_gemm_p8_launch(d, st);
     else if (big) ns_gemm_ring256_launch(d, st);
     else ns_gemm_ring_launch(d, st);

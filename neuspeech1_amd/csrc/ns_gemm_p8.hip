@@ -120,6 +120,15 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
   // written) straight into MFMA operand registers and multiplied while the prologue's LDS-DMA pieces are in flight.
   const int nsteps = (p.K + BK - 1) / BK;
 
+#ifndef NS_P8_GLOBAL_DMA
+  // LDS-DMA pieces as buffer loads: the per-lane part of the address is a 32-bit byte offset computed once per tile, the
+  // K position rides in the scalar offset, and a lane whose chunk lies past K (K tails, padding tiles) gets an offset
+  // beyond num_records, which the hardware range check turns into zeros -- one compare + one select per piece where the
+  // global_load form needed a 64-bit add and a 64-bit select against a block of zeros (the main loop is bound by each
+  // wave's own instruction stream: DESIGN.md §6).  Operands are < 2 GiB (checked by the launcher).
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x80000000u, 0x00020000);
+#endif
   auto stage = [&](int tt, int region, int buf) __attribute__((always_inline)) {
     const int k0 = tt * BK;
     int klen = p.K - k0;                    // <= 0 past the end (padding tiles): fetched as zeros
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     const int h = region & 1;
     const bool isb = region >= 2;
     char* const dst = smem + buf * BUF + region * REGION + wave * 2048;
+#ifdef NS_P8_GLOBAL_DMA
     const half_t* const base = (const half_t*)(isb ? p.B : p.A);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -136,6 +146,15 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
       const bool ok = my_chunk[j] * 8 < klen;
       glds16(ok ? base + (size_t)off + k0 : (const half_t*)ns_p8_zero_chunk, dst + j * 1024);
     }
+#else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t off = isb ? b_src[h][j] : a_src[h][j];
+      const bool ok = my_chunk[j] * 8 < klen;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isb ? rsrc_b : rsrc_a, (lds_void*)(dst + j * 1024), 16, ok ? 2u * off : 0x80000000u,
+                                               2 * k0, 0, 0);
+    }
+#endif
   };
 
   // fragment addresses: row (16-row tile base + l15), chunk (4*ks + lg) ^ (l15 >> 1)  =>  k-step 1 = address ^ 64
@@ -460,6 +479,16 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 }
 
 }  // namespace
+
+// operands addressed with 32-bit byte offsets (buffer loads): the last row's end must stay below 2 GiB
+bool ns_gemm_p8_fits(const ns_gemm_desc* d) {
+  const auto extent = [](const ns_rowmap& m, int rows, int k) -> long long {
+    const long long last = m.seg_rows > 0 ? (long long)((rows - 1) / m.seg_rows) * m.seg_stride + (long long)((rows - 1) % m.seg_rows) * m.ld
+                                          : (long long)(rows - 1) * m.ld;
+    return 2 * (last + k + 64);
+  };
+  return extent(d->am, d->M, d->K) < 0x7FFF0000LL && extent(d->bm, d->N, d->K) < 0x7FFF0000LL;
+}
 
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);

@@ -115,6 +115,13 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
     for (int it = 0; it < LB; ++it)
       *(uint4*)(Bs + buf * B_BYTES + (tid / CB + it * (NTH / CB)) * SB + cb * 16) = rb[it];
   };
+  // NS_GEMM_COLSUM_A: the workgroups of the first column tile also sum the A columns over the reduction (the bias
+  // gradient of a conv: column sums of d(pre), which used to be a separate pass over the same bytes): the transposed
+  // fragment of lane (column, half) holds 8 reduction rows of that column
+  const bool colsum = (p.flags & NS_GEMM_COLSUM_A) && tj == 0 && wj == 0;
+  float csum[TI];
+#pragma unroll
+  for (int a = 0; a < TI; ++a) csum[a] = 0.f;
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* as = As + buf * A_BYTES;
     const char* bs = Bs + buf * B_BYTES;
@@ -123,6 +130,12 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
       half8 af[TI], bf[TJ];
 #pragma unroll
       for (int a = 0; a < TI; ++a) af[a] = tr_frag(as, SA, 16 * s, wi * WI + a * 32, lane);
+      if (colsum) {
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[a] += (float)af[a][e];
+      }
 #pragma unroll
       for (int b = 0; b < TJ; ++b) bf[b] = tr_frag(bs, SB, 16 * s, wj * WJ + b * 32, lane);
 #pragma unroll
@@ -150,6 +163,14 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
 
   const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
   const bool atomic32 = p.flags & NS_GEMM_ATOMIC32;
+  if (colsum) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a) {
+      const float t = csum[a] + __shfl_xor(csum[a], 32, 64);      // the two k halves of the column
+      const int row = i0 + wi * WI + a * 32 + lr;
+      if (lh == 0 && row < p.M) atomicAdd(p.H32 + row, t * alpha);
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll

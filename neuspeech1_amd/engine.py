@@ -29,7 +29,7 @@ import torch
 from . import ops
 from .feed import PackedSignal
 from .lib import AdamWCfg
-from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN,
+from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_COLSUM_A, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN,
                   rowmap)
 
 # Every GELU site saves gelu'(x) (fp16) where the reference keeps x for autograd: the backward seams then multiply
@@ -544,16 +544,18 @@ class MegWhisperEngine:
         return 256.0 / (256.0 - int(p * 256.0 + 0.5)) if p > 0 else 1.0
 
     def _wgrad(self, dy16, ldy, x16, ldx, Mred, No, Ko, gname, alpha=1.0, goff=0, ldc=None, drop=False,
-               am=None, bm=None):
+               am=None, bm=None, bias_gname=None):
+        """bias_gname: also accumulate the column sums of dy (a conv's bias gradient) from the same pass"""
         gptr = self.G.data_ptr() + 4 * (self.seg_off[gname][0] + goff)
         tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
         # blocks in flight: ~1.5 per CU for the 128 x 32 tiles of dB (more splits only add atomics: 23 us at 384 blocks,
         # 30 us at 768 for N = 512), ~3 per CU for the others (tools/probe/tn_splits.py)
         target = 384 if (Ko <= 96 or 32 < No <= 128) else 768
         splits = max(1, min(Mred // 256, (target + tiles - 1) // tiles))
+        bptr = self.G.data_ptr() + 4 * self.seg_off[bias_gname][0] if bias_gname else None
         ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
-                 ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=splits, alpha=alpha,
-                 drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
+                 ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32 | (NS_GEMM_COLSUM_A if bias_gname else 0), splits=splits,
+                 alpha=alpha, H32=bptr, drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
 
     # ------------------------------------------------------------------ forward
     def _mark(self, name):
@@ -940,8 +942,9 @@ class MegWhisperEngine:
         ops.dgelu_mul(b["dh16"], b["pre2"], (b["dpre2"], d), rowmap(d, S, (S + 2) * d), M, d, pre_is_grad=True)
         dp2 = (b["dpre2"], d)
         hal2 = rowmap(d, S, (S + 2) * d)
-        ops.colsum(b["dpre2"], gp("model.encoder.conv2.bias"), B * (S + 2), d, d)
-        self._wgrad(dp2, 0, b["g1"], 0, M, d, 3 * d, "model.encoder.conv2.wp", am=hal2, bm=rowmap(2 * d, S, (T2 + 2) * d))
+        # the bias gradients (column sums of d(pre)) ride on the weight-gradient GEMMs that stream the same rows
+        self._wgrad(dp2, 0, b["g1"], 0, M, d, 3 * d, "model.encoder.conv2.wp", am=hal2, bm=rowmap(2 * d, S, (T2 + 2) * d),
+                    bias_gname="model.encoder.conv2.bias")
         # dgrad of the stride-2 conv: even output rows (tap 1), odd rows (taps 2|0 over dy[i], dy[i+1])
         # gelu'(pre1) is applied in the epilogue; results land directly in the halo layout of d(pre1)
         ev = rowmap(2 * d, S, T2 * d)
@@ -953,22 +956,19 @@ class MegWhisperEngine:
         dp1 = (b["dpre1"], d)
         hal1 = rowmap(d, T2, (T2 + 2) * d)
         if self.frontend == "replace":
-            ops.colsum(b["dpre1"], gp("model.encoder.conv1.bias"), B * (T2 + 2), d, d)
             self._wgrad(dp1, 0, b["xin_cur"], 0, B * T2, d, 3 * Cp, "model.encoder.conv1.wp", am=hal1,
-                        bm=rowmap(2 * Cp, T2, (T + 2) * Cp))
+                        bm=rowmap(2 * Cp, T2, (T + 2) * Cp), bias_gname="model.encoder.conv1.bias")
             return
         c1 = self.conv_ops["conv1.2"]
-        ops.colsum(b["dpre1"], gp("model.encoder.conv1.2.bias"), B * (T2 + 2), d, d)
         self._wgrad(dp1, 0, b["g0"], 0, B * T2, d, 3 * d, "model.encoder.conv1.2.wp", am=hal1,
-                    bm=rowmap(2 * d, T2, (T + 2) * d))
+                    bm=rowmap(2 * d, T2, (T + 2) * d), bias_gname="model.encoder.conv1.2.bias")
         ev = rowmap(2 * d, T2, T * d)
         ops.gemm(A=dp1, am=hal1, K=d, B=c1["we"], ldb=d, M=B * T2, N=d, C16=b["dpre0"], c16m=ev, P16=b["pre0"], p16m=ev,
                  flags=NS_GEMM_MUL_P16)
         ops.gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
                  P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
-        ops.colsum(b["dpre0"], gp("model.encoder.conv1.0.bias"), B * T, d, d)
         self._wgrad(b["dpre0"], 0, b["xin_cur"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
-                    bm=rowmap(Cp, T, (T + 2) * Cp))
+                    bm=rowmap(Cp, T, (T + 2) * Cp), bias_gname="model.encoder.conv1.0.bias")
 
     # ------------------------------------------------------------------ optimizer
     def zero_grad(self):

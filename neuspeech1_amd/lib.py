@@ -145,7 +145,7 @@ class BeamDesc(C.Structure):
 
 
 NS_GEMM_GELU, NS_GEMM_DGELU, NS_GEMM_TN, NS_GEMM_ATOMIC32, NS_GEMM_DROP_A = 1, 2, 4, 8, 16
-NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16 = 32, 64
+NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_COLSUM_A = 32, 64, 128
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 

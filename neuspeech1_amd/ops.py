@@ -7,13 +7,13 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (AdamWCfg, AttnDesc, CastJob, GemmDesc, RowMap, NS_GEMM_ATOMIC32, NS_GEMM_DGELU, NS_GEMM_DROP_A,
+from .lib import (AdamWCfg, AttnDesc, CastJob, GemmDesc, RowMap, NS_GEMM_ATOMIC32, NS_GEMM_COLSUM_A, NS_GEMM_DGELU, NS_GEMM_DROP_A,
                   NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN)
 
 __all__ = ["gemm", "rowmap", "ptr", "layernorm_fwd", "layernorm_bwd", "signal_pack", "feed_pack", "embed_pos", "attn_fwd",
            "attn_bwd", "cross_entropy", "dgelu_mul", "colsum", "argmax_rows", "grad_norm", "adamw_step", "cast_jobs", "make_cast_jobs",
            "NS_GEMM_GELU", "NS_GEMM_DGELU", "NS_GEMM_TN", "NS_GEMM_ATOMIC32", "NS_GEMM_DROP_A", "NS_GEMM_GELU_SAVE_GRAD",
-           "NS_GEMM_MUL_P16"]
+           "NS_GEMM_MUL_P16", "NS_GEMM_COLSUM_A"]
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

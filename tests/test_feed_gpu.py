@@ -78,5 +78,9 @@ def test_training_step_from_the_feed_matches_the_tensor_path(dev, tmp_path):
     la, pa = run(False)
     lb, pb = run(True)
     # identical operands -> identical kernels; only the fp32 atomics of the weight gradients reorder
+    # (run-to-run, tools/probe/feed_repeat.py: AdamW's first update is lr * sign(g), so an adapter entry whose gradient is within
+    # the atomics' last-bit noise of zero lands on +lr in one run and -lr in the next and drags a few neighbours by ~2e-4; the
+    # SAME spread shows between two runs of the tensor path alone)
     np.testing.assert_allclose(la, lb, rtol=2e-4)
-    assert (pa - pb).abs().max().item() < 5e-4
+    diff = (pa - pb).abs()
+    assert diff.max().item() < 2.5e-3 and (diff > 1e-5).float().mean().item() < 2e-2, (diff.max().item(), (diff > 1e-5).float().mean().item())

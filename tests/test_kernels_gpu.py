@@ -201,6 +201,14 @@ def test_gemm_tn_conv_wgrad(ops, dev):
     y.backward(dy.float().reshape(Bn, Tout, Cout).transpose(1, 2))
     ref = w.grad.permute(0, 2, 1).reshape(Cout, 3 * Cin)
     close(out, ref, 2e-2, 2e-3, "conv wgrad")
+    # the bias gradient (column sums of dy) as a side output of the same pass, accumulated onto a non-zero buffer
+    out2 = torch.zeros_like(out)
+    bg = torch.full((Cout,), 0.5, device=dev)
+    ops.gemm(A=dy, am=ops.rowmap(Cout, Tout, Tout * Cout), K=Bn * Tout, B=xh,
+             bm=ops.rowmap(stride * Cin, Tout, (T + 2) * Cin), M=Cout, N=3 * Cin, C32=out2, ldc32=3 * Cin,
+             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32 | ops.NS_GEMM_COLSUM_A, splits=3, H32=bg)
+    close(out2, ref, 2e-2, 2e-3, "conv wgrad (with column sums)")
+    close(bg, 0.5 + dy.float().sum(0), 2e-3, 1e-3, "bias gradient from the weight-gradient pass")
 
 
 # --------------------------------------------------------------------------- LayerNorm
