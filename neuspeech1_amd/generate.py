@@ -60,14 +60,16 @@ def _sequence_bias_tables(sequence_bias, V, dev):
 
 
 class Generator:
-    def __init__(self, engine, use_graph: bool = True, graph_min_steps: int = 24, cross_mfma: bool = True):
+    def __init__(self, engine, use_graph: bool = True, graph_min_steps: int | None = None, cross_mfma: bool = True):
         self.eng = engine
         self.use_graph = use_graph
         self.cross_mfma = cross_mfma    # beam cross-attention through ns_attn_fewq (False: the flash kernel)
-        # capturing the four graphs costs ~3-4 ms; measured on MI355X the decode loop is GPU-bound (B=128: replay and
-        # eager launches give the same tokens/s), so graphs only insure against a slow / contended host and are
-        # skipped for short generations
-        self.graph_min_steps = graph_min_steps
+        # capturing the four graphs costs ~3 ms; measured on MI355X the decode loop is GPU-bound (B = 128: a replayed step
+        # and an eagerly launched one take the same time), so graphs only insure against a slow / contended host.  At 64
+        # new tokens the capture is never paid back (tools/probe/gen_timing.py: 82.0 vs 78.9 ms greedy, 104.6 vs 101.7 ms
+        # beam-5), so only generations with >= 128 steps left (whisper's max_length is 448) capture
+        import os
+        self.graph_min_steps = int(os.environ.get("NS_GRAPH_MIN_STEPS", 128)) if graph_min_steps is None else graph_min_steps
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,

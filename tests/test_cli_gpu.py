@@ -310,11 +310,13 @@ def test_finetune_with_default_timestamp_labels_at_whisper_base_dims(dev, tmp_pa
     assert len(logs) == 3 and all(np.isfinite(l["loss"]) for l in logs) and logs[-1]["loss"] < logs[0]["loss"] + 0.5, logs
 
 
-def test_evaluation_graph_replay_with_the_feed_thread_running(dev, tmp_path):
-    """Long enough generations use hipGraph replay (Generator.graph_min_steps); the on-GPU feed stages the NEXT batch
-    from its loader thread while a capture is in progress (thread-local capture mode).  Same hypotheses as the host
-    reader path without graphs in the way."""
+def test_evaluation_graph_replay_with_the_feed_thread_running(dev, tmp_path, monkeypatch):
+    """Long enough generations use hipGraph replay (Generator.graph_min_steps: 128 steps by default, lowered here through
+    NS_GRAPH_MIN_STEPS so that a 40-token generation captures); the on-GPU feed stages the NEXT batch from its loader
+    thread while a capture is in progress (thread-local capture mode).  Same hypotheses as the host reader path without
+    graphs in the way."""
     import evaluation
+    monkeypatch.setenv("NS_GRAPH_MIN_STEPS", "16")
     from neuspeech1_amd.synthetic import write_synthetic_dataset
     jl = write_synthetic_dataset(str(tmp_path / "data"), 20, ch_file=24, name="toyset", seed=9, min_len=120, max_len=520)
     common = [f"--test_data={jl}", "--model_path=synthetic:tiny", "--modal=eeg", "--eeg_ch=20", "--sampling_rate=200",
