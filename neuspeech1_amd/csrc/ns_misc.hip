@@ -15,22 +15,40 @@ extern "C" const char* ns_last_error(void) { return g_err; }
 
 namespace {
 
-// (B, ch, T) fp32 channel-major  ->  (B, T+2, Cp) fp16 token-major with a zero
-// halo row at both ends and zero channel padding.  Reads are coalesced along T
-// (256 B per wave-instruction), writes are 16 B per lane along the channel axis.
-// Block = 256 threads handles 64 time steps x 64 channels through an LDS tile.
+// (B, ch, T) fp32 channel-major  ->  (B, T+2, Cp) fp16 token-major with a zero halo row at both ends and zero channel
+// padding.  The only full-size read of the batch: 16-B lane loads along T (a wave instruction covers 4 channel rows x
+// 256 B; T % 4 == 0 keeps every row 16-B aligned, else the scalar form below), transposed through an LDS tile stored
+// [time][channel] so that each lane leaves with ONE ds_read_b128 and ONE 16-B store along the channel axis.
+// Block = 256 threads handles 64 time steps x 64 channels.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restrict__ x, half_t* __restrict__ out, int ch,
                                                            int T, int Cp) {
-  __shared__ half_t tile[64][66];  // [channel][time], +2 pad
+  constexpr int LDT = 72;                               // halfs per tile row: 144 B keeps 16-B alignment and spreads the banks
+  __shared__ __attribute__((aligned(16))) half_t tile[64 * LDT];     // [time][channel]
   const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* xb = x + (size_t)b * ch * T;
+  if (VEC4) {
+    const int cl = threadIdx.x >> 4, tl4 = (threadIdx.x & 15) * 4;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + cl + 16 * i, t = t0 + tl4;
+      v[i] = (c < ch && t < T) ? *(const float4*)(xb + (size_t)c * T + t) : make_float4(0.f, 0.f, 0.f, 0.f);   // T % 4 == 0: t + 3 < T
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      half_t* col = tile + tl4 * LDT + cl + 16 * i;
+      col[0] = (half_t)v[i].x; col[LDT] = (half_t)v[i].y; col[2 * LDT] = (half_t)v[i].z; col[3 * LDT] = (half_t)v[i].w;
+    }
+  } else {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int c = c0 + w * 16 + i, t = t0 + lane;
-    float v = 0.f;
-    if (c < ch && t < T) v = xb[(size_t)c * T + t];
-    tile[w * 16 + i][lane] = (half_t)v;
+    for (int i = 0; i < 16; ++i) {
+      const int c = c0 + w * 16 + i, t = t0 + lane;
+      float v = 0.f;
+      if (c < ch && t < T) v = xb[(size_t)c * T + t];
+      tile[lane * LDT + w * 16 + i] = (half_t)v;
+    }
   }
   __syncthreads();
   half_t* ob = out + (size_t)b * (T + 2) * Cp;
@@ -39,12 +57,7 @@ __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restric
   for (int it = 0; it < 2; ++it) {
     const int tl = (threadIdx.x >> 3) + 32 * it;
     const int t = t0 + tl;
-    if (t < T) {
-      half8 h;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = tile[cc + e][tl];
-      *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = h;
-    }
+    if (t < T) *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = *(const half8*)(tile + tl * LDT + cc);
   }
   // halo rows
   if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -295,7 +308,10 @@ extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T,
   NS_CHECK_ARG(x && out16, "ns_signal_pack: null pointer");
   NS_CHECK_ARG(B > 0 && ch > 0 && T > 0 && Cp >= ch && Cp % 64 == 0, "ns_signal_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
   dim3 grid((T + 63) / 64, Cp / 64, B);
-  hipLaunchKernelGGL(signal_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
+  if (T % 4 == 0 && ((uintptr_t)x & 15) == 0)
+    hipLaunchKernelGGL(signal_pack_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
+  else
+    hipLaunchKernelGGL(signal_pack_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
   NS_CHECK_LAUNCH("ns_signal_pack");
   return NS_OK;
 }

@@ -239,7 +239,7 @@ def test_layernorm(ops, dev, rows, d):
 
 
 # --------------------------------------------------------------------------- byte movers
-@pytest.mark.parametrize("ch,T", [(208, 6000), (273, 6000), (10, 100)])
+@pytest.mark.parametrize("ch,T", [(208, 6000), (273, 6000), (10, 100), (20, 402), (70, 130)])
 def test_signal_pack(ops, dev, ch, T):
     Bn = 2
     Cp = (ch + 63) // 64 * 64
