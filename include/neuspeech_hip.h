@@ -227,7 +227,11 @@ typedef struct {
   int32_t ldy, ldu, lddu, lddb;
   float alpha_du; float alpha_db[3];
   int32_t splits;
+  /* optional: with a workspace of ns_lora_bwd_workspace_bytes(M, N, G, splits) bytes the per-workgroup dB partials go
+   * through plain stores + a small reduce launch instead of fp32 atomics (the result is then also bitwise reproducible) */
+  void* workspace; size_t workspace_bytes;
 } ns_lora_bwd_desc;
+size_t ns_lora_bwd_workspace_bytes(int M, int N, int G, int splits);
 int ns_lora_bwd_supported(int N, int r, int G);
 int ns_lora_bwd_dudb(const ns_lora_bwd_desc* d, void* stream);
 

@@ -18,16 +18,19 @@
 
 namespace {
 
-constexpr int RC = 64, SC = 256, NTH = 512;
-constexpr int DY_BYTES = RC * SC * 2;        // 32 KiB
+constexpr int RC = 64, SC = 256, NTH = 512, NBUF = 3;
+constexpr int DY_BYTES = RC * SC * 2;        // 32 KiB: dy slice, 64 rows x 512 B
+constexpr int SB_BYTES = 32 * SC * 2;        // 16 KiB: sB^T slice, 32 bottleneck rows x 512 B
+constexpr int SLOT_BYTES = DY_BYTES + SB_BYTES;
 constexpr int U_STRIDE = 64;                 // bytes per u row image (32 halfs)
 constexpr int U_BYTES = RC * U_STRIDE;       // 4 KiB
-constexpr int RED_BYTES = 8 * 32 * 32 * 4;   // du partials of the 8 waves
-constexpr int LDS_BYTES = 2 * DY_BYTES + 2 * U_BYTES + RED_BYTES;
+constexpr int LDS_BYTES = NBUF * SLOT_BYTES + 3 * U_BYTES;   // 156 KiB
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) short4v lds_s4;
+
+__device__ __attribute__((aligned(16))) const uint32_t ns_lb_zero_chunk[4] = {0, 0, 0, 0};
 
 __device__ __forceinline__ int dy_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 31)) << 4); }
 
@@ -43,19 +46,49 @@ __device__ __forceinline__ half8 tr_frag(const char* tile, Off off, int m0, int 
   return __builtin_bit_cast(half8, r);
 }
 
+// LDS-DMA as inline asm.  With the builtin hipcc knows that an LDS write is pending on the vm counter and, the ring
+// slots being runtime-indexed, fences the loop's ds_read / ds_write with s_waitcnt vmcnt(0) -- which drains the items in
+// flight.  Hidden in asm, the transfers are ordered by this kernel's own counted waits and raw barriers only.  M0 carries
+// the wave-uniform LDS byte address and is saved / restored inside the statement (cdna guide §5.7).
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+#define NS_LB_BARRIER()                                   \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("" ::: "memory");                        \
+  } while (0)
+
+// Every operand of an item -- the dy slice (64 x 256), the sB^T slice (32 x 256) and, at a group's first slice, the chunk's
+// u rows -- travels by LDS-DMA into a ring of three slots, issued TWO items ahead of the one being multiplied: no staging
+// registers, ~100 KiB in flight per CU, and no register load in the loop for hipcc to fence.  The swizzle sits on the
+// per-lane SOURCE address (LDS chunk c' of row r <- global chunk c' ^ (r & 31)).  A wave issues 6 pieces per item (+ 2
+// four-byte pieces of u at a group's first slice); the counted wait at the top of an iteration leaves exactly the pieces of
+// the NEXT-BUT-ONE item in flight.
 template <int G, int NSUB>
 __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const dyb = smem;
-  char* const ub = smem + 2 * DY_BYTES;
-  float* const red = (float*)(smem + 2 * DY_BYTES + 2 * U_BYTES);
+  char* const ring = smem;
+  char* const ub = smem + NBUF * SLOT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int nchunks = (p.M + RC - 1) / RC;
   const int per = (nchunks + (int)gridDim.x - 1) / (int)gridDim.x;
   const int c_lo = blockIdx.x * per, c_hi = min(nchunks, c_lo + per);
+  constexpr int IPC = G * NSUB;                  // items per chunk
+  const int nitems = max(c_hi - c_lo, 0) * IPC;
 
   f32x16 accB[G][NSUB];
 #pragma unroll
@@ -64,77 +97,84 @@ __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_de
     for (int s = 0; s < NSUB; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accB[g][s][r] = 0.f;
-  f32x16 accU;
+  f32x16 accU;                                   // waves 0 / 1: du of chunk rows 0..31 / 32..63, all columns of the group
 #pragma unroll
   for (int r = 0; r < 16; ++r) accU[r] = 0.f;
 
-  // staging registers of the NEXT item
-  uint4 dyr[4];
-  half8 sbr[4];
-  uint4 ur;
-  const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int mt = wave & 1, kq = wave >> 1;
-
-  auto load_item = [&](int c, int g, int s) __attribute__((always_inline)) {
+  // 6 (+2) pieces per wave: dy rows [8w, 8w+8) (4 x 1 KiB), sB^T rows [4w, 4w+4) (2 x 1 KiB), u rows [8w, 8w+8) (2 x 256 B)
+  auto issue = [&](int c, int g, int s, int slot) __attribute__((always_inline)) {
     const int row0 = c * RC;
-    const half_t* dy = (const half_t*)p.dy + (long long)g * p.N + s * SC;
+    int col0 = g * p.N + s * SC, scol0 = s * SC;
+    asm volatile("" : "+s"(col0), "+s"(scol0));      // opaque: keeps hipcc from hoisting one pointer set per unrolled position
+    const half_t* dy = (const half_t*)p.dy + col0;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT_BYTES + wave * 4096);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int id = tid + NTH * i, row = id >> 5, ch = id & 31;
-      dyr[i] = row0 + row < p.M ? *(const uint4*)(dy + (long long)(row0 + row) * p.ldy + ch * 8) : make_uint4(0, 0, 0, 0);
+      const int row = 8 * wave + 2 * i + lh, cl = lr ^ (row & 31);
+      const void* src = row0 + row < p.M ? (const void*)(dy + (long long)(row0 + row) * p.ldy + cl * 8) : (const void*)ns_lb_zero_chunk;
+      glds16_asm(src, dst + i * 1024);
     }
-    if (s == 0 && tid < 256) {      // the chunk's u rows of this group (64 x r), one 16-B piece per thread
-      const int row = tid >> 2, cc = tid & 3;
-      const bool ok = row0 + row < p.M && cc * 8 < p.r;
-      ur = ok ? *(const uint4*)((const half_t*)p.u + (long long)(row0 + row) * p.ldu + g * p.r + cc * 8) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  // sB^T fragments of this wave's 64 slice columns: B[k = column][j]: lane (j = lr, half lh) holds 8 consecutive columns.
-  // Loaded for the NEXT item right after the current item's du MFMAs have consumed the registers (L2-resident operand).
-  auto load_sb = [&](int g, int s) __attribute__((always_inline)) {
-    const half_t* sbt = (const half_t*)p.sBT[g] + (long long)lr * p.N + s * SC + 64 * kq + 8 * lh;
+    const half_t* sbt = (const half_t*)p.sBT[g] + scol0;
+    const unsigned sdst = __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT_BYTES + DY_BYTES + wave * 2048);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sbr[ks] = lr < p.r ? *(const half8*)(sbt + 16 * ks) : hz;
-  };
-  auto store_item = [&](int it, int c, int g, int s) __attribute__((always_inline)) {
-    char* const buf = dyb + (it & 1) * DY_BYTES;
+    for (int i = 0; i < 2; ++i) {
+      const int row = 4 * wave + 2 * i + lh, cl = lr ^ (row & 31);       // bottleneck row j
+      const void* src = row < p.r ? (const void*)(sbt + (long long)row * p.N + cl * 8) : (const void*)ns_lb_zero_chunk;
+      glds16_asm(src, sdst + i * 1024);
+    }
+    if (s == 0) {
+      const unsigned udst = __builtin_amdgcn_readfirstlane(lds_base + NBUF * SLOT_BYTES + ((c * G + g) % 3) * U_BYTES + wave * 512);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + NTH * i, row = id >> 5, ch = id & 31;
-      *(uint4*)(buf + dy_off(row, ch)) = dyr[i];
-    }
-    if (s == 0 && tid < 256) {
-      const int slot = (c * G + g) & 1;
-      *(uint4*)(ub + slot * U_BYTES + (tid >> 2) * U_STRIDE + (tid & 3) * 16) = ur;
+      for (int i = 0; i < 2; ++i) {
+        const int row = 8 * wave + 4 * i + (lane >> 4), c2 = 2 * (lane & 15);   // 4 rows x 16 pieces of 2 halfs
+        const void* src = (row0 + row < p.M && c2 < p.r) ? (const void*)((const half_t*)p.u + (long long)(row0 + row) * p.ldu + g * p.r + c2)
+                                                          : (const void*)ns_lb_zero_chunk;
+        glds4_asm(src, udst + i * 256);
+      }
     }
   };
-  if (c_lo < c_hi) {
-    load_item(c_lo, 0, 0);
-    load_sb(0, 0);
-    store_item(0, c_lo, 0, 0);
+
+  // ---- prologue: items 0 and 1
+  if (nitems > 0) {
+    issue(c_lo, 0, 0, 0);
+    if (nitems > 1) {
+      constexpr int g1 = (1 % IPC) / NSUB, s1 = (1 % IPC) % NSUB;
+      issue(c_lo + 1 / IPC, g1, s1, 1);
+    }
   }
-  __syncthreads();
   int it = 0;
   for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int s = 0; s < NSUB; ++s, ++it) {
-        // the next item: (c, g, s + 1) -> (c, g + 1, 0) -> (c + 1, 0, 0)
-        const int ns = s + 1 < NSUB ? s + 1 : 0;
-        const int ng = s + 1 < NSUB ? g : (g + 1 < G ? g + 1 : 0);
-        const int nc = (s + 1 < NSUB || g + 1 < G) ? c : c + 1;
-        const bool more = nc < c_hi;
-        if (more) load_item(nc, ng, ns);
-        const char* const buf = dyb + (it & 1) * DY_BYTES;
-        const char* const uimg = ub + ((c * G + g) & 1) * U_BYTES;
-        // ---- du partial: rows 32*mt.., slice columns 64*kq.. (4 k-steps of 16)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const half8 a = *(const half8*)(buf + dy_off(32 * mt + lr, 8 * kq + 2 * ks + lh));
-          accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, sbr[ks], accU, 0, 0, 0);
+        // successors: linear positions l + 1, l + 2 within / past the chunk
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int l1 = g * NSUB + s + 1, l2 = g * NSUB + s + 2;
+        const int s1 = (l1 % IPC) % NSUB;
+        const int c2 = c + l2 / IPC, g2 = (l2 % IPC) / NSUB, s2 = (l2 % IPC) % NSUB;
+        const bool more1 = it + 1 < nitems, more2 = it + 2 < nitems;
+        // in flight behind item `it`: exactly the pieces of item it+1 (6, or 8 when it opens a group), issued last in the previous iteration
+        if (more1) {
+          if (s1 == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (more) load_sb(ng, ns);
+        NS_LB_BARRIER();      // every wave's pieces of item `it` have landed; the slot of item it-1 is free
+        const char* const buf = ring + (it % NBUF) * SLOT_BYTES;
+        const char* const sbuf = buf + DY_BYTES;
+        const char* const uimg = ub + ((c * G + g) % 3) * U_BYTES;
+        // ---- du: waves 0 and 1 own the chunk's two 32-row halves and walk all 256 slice columns (16 k-steps)
+        if (wave < 2) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const half8 a = *(const half8*)(buf + dy_off(32 * wave + lr, 2 * ks + lh));
+            const half8 bfr = *(const half8*)(sbuf + dy_off(lr, 2 * ks + lh));
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr, accU, 0, 0, 0);
+          }
+        }
         // ---- dB: dy columns 32*wave.. of this slice, reduction over the chunk's 64 rows
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -142,32 +182,44 @@ __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_de
           const half8 b = tr_frag(uimg, [](int row, int col) { return row * U_STRIDE + col * 2; }, 16 * ks, 0, lane);
           accB[g][s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, accB[g][s], 0, 0, 0);
         }
-        if (s == NSUB - 1) {
-          // ---- du of (chunk c, group g) is complete: sum the four column-quarter partials through LDS, scale, store
-          float* const mine = red + wave * 1024;
+        if (s == NSUB - 1 && wave < 2) {
+          // ---- du of (chunk c, group g) is complete in waves 0 / 1: accumulator (row = crow(r), column j = lr)
+          const int row0 = c * RC + 32 * wave;
+          if (lr < p.r) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = accU[r];
+            for (int r = 0; r < 16; ++r) {
+              const int m = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (m < p.M) ((half_t*)p.du)[(long long)m * p.lddu + g * p.r + lr] = (half_t)(accU[r] * p.alpha_du);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) accU[r] = 0.f;
-          __syncthreads();
-          const int row0 = c * RC;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int id = tid + NTH * i, m = id >> 5, j = id & 31;     // m: row of the chunk, j: bottleneck column
-            const int mtile = m >> 5, ml = m & 31;
-            float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v += red[(mtile + 2 * q) * 1024 + ml * 32 + j];
-            if (row0 + m < p.M && j < p.r)
-              ((half_t*)p.du)[(long long)(row0 + m) * p.lddu + g * p.r + j] = (half_t)(v * p.alpha_du);
-          }
         }
-        if (more) store_item(it + 1, nc, ng, ns);
-        __syncthreads();
+        // the next-but-one item goes out LAST in the iteration: at the next counted wait the youngest operations are then
+        // exactly its pieces (the du stores above are older).  Its ring slot held item it-1, which every wave left before
+        // this iteration's barrier; the u image slot (three of them) held the group three back.
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) issue(c2, g2, s2, (it + 2) % NBUF);
+        __builtin_amdgcn_sched_barrier(0);
       }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- dB leaves by fp32 atomics: accumulator tile (g, s): rows n = 256*s + 32*wave + crow(r), column j = lr
+  // ---- dB partials leave the workgroup: accumulator tile (g, s): rows n = 256*s + 32*wave + crow(r), column j = lr.
+  // With a workspace: plain stores into this workgroup's slab (G x N x 32 floats), summed by lora_bwd_reduce_kernel -- the
+  // atomics form moves N*r*4 B per workgroup through the ~1.3 TB/s atomic path (52 us of the fc1 site's 143 us).
+  if (p.workspace) {
+    float* const slab = (float*)p.workspace + (size_t)blockIdx.x * G * p.N * 32;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        float* const dst = slab + ((size_t)g * p.N + s * SC + 32 * wave) * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = accB[g][s][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -181,6 +233,33 @@ __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_de
         atomicAdd(dst + (long long)n * p.lddb, accB[g][s][r] * al);
       }
     }
+}
+
+// dB[g][n][j] += alpha_db[g] * sum over the workgroups' slabs.  A workgroup owns 16 consecutive float4 of a slab (256 B
+// per slab row); its 16 thread groups each sum every 16th slab and meet in LDS -- G*N/2 workgroups, so the d-wide site
+// (16.8 MB of slabs) still spreads over the whole chip.
+__global__ __launch_bounds__(256) void lora_bwd_reduce_kernel(const ns_lora_bwd_desc p, int nslabs) {
+  __shared__ float4 red[16][16];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int per = p.G * p.N * 8;                          // float4 per slab
+  const int q = blockIdx.x * 16 + c;
+  const float4* src = (const float4*)p.workspace + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w = grp; w < nslabs; w += 16) {
+    const float4 x = src[(size_t)w * per];
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+  }
+  red[grp][c] = a;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  // thread (c, e): element e of float4 c
+  const int cc = threadIdx.x >> 2, e = threadIdx.x & 3;
+  float v = 0.f;
+#pragma unroll
+  for (int gq = 0; gq < 16; ++gq) v += ((const float*)&red[gq][cc])[e];
+  const int qq = blockIdx.x * 16 + cc;
+  const int g = qq / (p.N * 8), rem = qq - g * p.N * 8, n = rem >> 3, j = (rem & 7) * 4 + e;
+  if (j < p.r) p.dB[g][(long long)n * p.lddb + j] += v * p.alpha_db[g];
 }
 
 template <int G, int NSUB>
@@ -201,6 +280,13 @@ extern "C" int ns_lora_bwd_supported(int N, int r, int G) {
   return nsub == 1 || nsub == 2;
 }
 
+extern "C" size_t ns_lora_bwd_workspace_bytes(int M, int N, int G, int splits) {
+  const int nchunks = (M + RC - 1) / RC;
+  int grid = splits > 0 ? splits : 256;
+  if (grid > nchunks) grid = nchunks;
+  return (size_t)grid * G * N * 32 * sizeof(float);
+}
+
 extern "C" int ns_lora_bwd_dudb(const ns_lora_bwd_desc* d, void* stream) {
   NS_CHECK_ARG(d && d->dy && d->u && d->du, "ns_lora_bwd_dudb: null pointer");
   NS_CHECK_ARG(d->M > 0 && ns_lora_bwd_supported(d->N, d->r, d->G),
@@ -213,11 +299,16 @@ extern "C" int ns_lora_bwd_dudb(const ns_lora_bwd_desc* d, void* stream) {
   const int nchunks = (d->M + RC - 1) / RC;
   int grid = d->splits > 0 ? d->splits : 256;
   if (grid > nchunks) grid = nchunks;
+  NS_CHECK_ARG(!d->workspace || d->workspace_bytes >= (size_t)grid * d->G * d->N * 32 * sizeof(float),
+               "ns_lora_bwd_dudb: workspace of %zu bytes is smaller than ns_lora_bwd_workspace_bytes()", (size_t)d->workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   const int nsub = d->N / SC;
 #define NS_LB(G_, S_) if (d->G == G_ && nsub == S_) { launch<G_, S_>(d, grid, st); }
   NS_LB(1, 1) else NS_LB(1, 2) else NS_LB(1, 5) else NS_LB(1, 8) else NS_LB(3, 1) else NS_LB(3, 2)
 #undef NS_LB
+  if (d->workspace) {
+    hipLaunchKernelGGL(lora_bwd_reduce_kernel, dim3(d->G * d->N / 2), dim3(256), 0, st, *d, grid);
+  }
   NS_CHECK_LAUNCH("ns_lora_bwd_dudb");
   return NS_OK;
 }

@@ -126,6 +126,7 @@ class LoraBwdDesc(C.Structure):
         ("ldy", C.c_int32), ("ldu", C.c_int32), ("lddu", C.c_int32), ("lddb", C.c_int32),
         ("alpha_du", C.c_float), ("alpha_db", C.c_float * 3),
         ("splits", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -167,6 +168,7 @@ SIGNATURES = {
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
     "ns_lora_bwd_supported": (C.c_int, [_i, _i, _i]),
+    "ns_lora_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ns_lora_bwd_dudb": (C.c_int, [C.POINTER(LoraBwdDesc), _vp]),
     "ns_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),

@@ -286,9 +286,20 @@ def lora_bwd_supported(N: int, r: int, G: int) -> bool:
     return bool(L.load().ns_lora_bwd_supported(N, r, G))
 
 
-def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du, alpha_db, splits=0):
-    """sBT / dB / alpha_db: one entry per column group of dy (q | k | v: three, else one)"""
+_lora_ws = {}
+
+
+def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du, alpha_db, splits=0, slabs=True):
+    """sBT / dB / alpha_db: one entry per column group of dy (q | k | v: three, else one).  slabs: dB partials through a
+    workspace + reduce launch (one cached workspace per device, sized for the largest request) instead of fp32 atomics"""
     d = L.LoraBwdDesc()
+    if slabs:
+        need = L.load().ns_lora_bwd_workspace_bytes(M, N, len(sBT), splits)
+        ws = _lora_ws.get(du.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=du.device, dtype=torch.uint8)
+            _lora_ws[du.device] = ws
+        d.workspace, d.workspace_bytes = ptr(ws), ws.numel()
     d.dy, d.u, d.du = ptr(dy), ptr(u), ptr(du)
     G = len(sBT)
     for g in range(G):

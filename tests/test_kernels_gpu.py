@@ -636,10 +636,12 @@ def test_dominant_gemm_at_bench_size_against_torch(ops, dev, name, N, K, kind):
 
 @pytest.mark.parametrize("M,N,r,G,splits", [(1000, 512, 32, 1, 0), (520, 256, 16, 3, 3), (777, 2048, 32, 1, 5), (4096, 512, 32, 3, 0),
                                             (333, 1280, 32, 1, 2), (64, 256, 32, 1, 0), (96000, 512, 32, 3, 0)])
-def test_lora_backward_du_and_dB_in_one_pass(ops, dev, M, N, r, G, splits):
+@pytest.mark.parametrize("slabs", [True, False])
+def test_lora_backward_du_and_dB_in_one_pass(ops, dev, M, N, r, G, splits, slabs):
     """ns_lora_bwd_dudb (du_g = alpha dy_g sB_g and dB_g += alpha_g dy_g^T u_g from ONE pass over dy) against torch fp32,
     ragged row counts, every built (N, G) shape class, the padded rank 16, accumulation into a non-zero dB, and the
-    bench size M = 96 000 (q | k | v)."""
+    bench size M = 96 000 (q | k | v); dB partials through the workspace slabs + reduce launch, and through fp32 atomics.
+    The slab form is bitwise reproducible."""
     assert ops.lora_bwd_supported(N, r, G) and not ops.lora_bwd_supported(N + 8, r, G) and not ops.lora_bwd_supported(N, 24, G)
     dy = rnd((M, G * N), dev, 0.5, seed=1)
     u = rnd((M, G * r), dev, 0.5, seed=2)
@@ -649,7 +651,12 @@ def test_lora_backward_du_and_dB_in_one_pass(ops, dev, M, N, r, G, splits):
     du = torch.full((M, G * r), float("nan"), device=dev, dtype=torch.float16)
     al = [0.7, 1.3, 2.0][:G]
     ops.lora_bwd_dudb(dy=dy, ldy=G * N, u=u, ldu=G * r, du=du, lddu=G * r, sBT=sBT, dB=dB, lddb=r, M=M, N=N, r=r, alpha_du=1.25,
-                      alpha_db=al, splits=splits)
+                      alpha_db=al, splits=splits, slabs=slabs)
+    if slabs:
+        dB2 = [t.clone() for t in dB0]
+        ops.lora_bwd_dudb(dy=dy, ldy=G * N, u=u, ldu=G * r, du=du, lddu=G * r, sBT=sBT, dB=dB2, lddb=r, M=M, N=N, r=r, alpha_du=1.25,
+                          alpha_db=al, splits=splits, slabs=True)
+        assert all(torch.equal(a, b) for a, b in zip(dB, dB2))
     for g in range(G):
         dyg = dy[:, g * N:(g + 1) * N].float()
         close(du[:, g * r:(g + 1) * r], 1.25 * dyg @ sBT[g].float().T, 2e-2 * (N / 512) ** 0.5, 4e-3, f"du group {g}")

@@ -162,3 +162,16 @@ for name, n_, k_ in (("dec 2816x512x512", d, d), ("dec 2816x1536x512", 3 * d, d)
     a_, w_ = rnd(MLd, k_), rnd(n_, k_, scale=0.04)
     o_ = torch.empty(MLd, n_, device=dev, dtype=F16)
     timeit(name, lambda: ops.gemm(A=a_, am=rowmap(k_), K=k_, B=w_, ldb=k_, M=MLd, N=n_, C16=o_, c16m=rowmap(n_)), 2.0 * MLd * n_ * k_)
+
+# fused adapter backward (du + dB from one pass over dy): the three site shapes, workgroup count sweep
+for name, G_, N_ in (("lora_bwd qkv G=3 N=512", 3, d), ("lora_bwd d-wide N=512", 1, d), ("lora_bwd fc1 N=2048", 1, f)):
+    dy_ = rnd(M, G_ * N_, scale=0.5)
+    u_ = rnd(M, G_ * r, scale=0.5)
+    du_ = torch.empty(M, G_ * r, device=dev, dtype=F16)
+    sBT_ = [rnd(r, N_, scale=0.1) for _ in range(G_)]
+    dB_ = [torch.zeros(N_, r, device=dev) for _ in range(G_)]
+    for sp, slabs in ((128, False), (256, False), (512, False), (256, True), (512, True)):
+        timeit(f"{name} splits={sp} {'slabs' if slabs else 'atomics'}",
+               lambda: ops.lora_bwd_dudb(dy=dy_, ldy=G_ * N_, u=u_, ldu=G_ * r, du=du_, lddu=G_ * r, sBT=sBT_, dB=dB_, lddb=r, M=M, N=N_, r=r,
+                                         alpha_du=1.0, alpha_db=[1.0] * G_, splits=sp, slabs=slabs),
+               0.0, M * G_ * N_ * 2)
