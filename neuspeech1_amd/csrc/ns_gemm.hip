@@ -358,6 +358,8 @@ int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_p8_fits(const ns_gemm_desc* d);
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
+int ns_gemm_skinny_launch(const ns_gemm_desc* d, hipStream_t st);
+bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -429,6 +431,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
   } else if (!tn && d->splits > 1) {
     ns_gemm_ring_launch(d, st);
+  } else if (g_use_ring != 0 && g_use_ring != 7 && ns_gemm_skinny_ok(d)) {
+    ns_gemm_skinny_launch(d, st);   // LoRA down-projections at training size: one stream over x (mode 7 = off, for A/B runs)
   } else if (g_use_ring != 6 && g_use_ring != 0 && ns_gemm_smallm_ok(d)) {
     ns_gemm_smallm_launch(d, st);   // decode shapes: 32x32 tiles, K split over the four waves (mode 6 = off, for A/B runs)
   } else if (skinny) {

@@ -437,6 +437,33 @@ def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
     lib.load().ns_debug_set_ring(1)
 
 
+@pytest.mark.parametrize("M,K,N,p", [(8200, 512, 32, 0.05), (9001, 512, 96, 0.05), (8192, 2048, 32, 0.05), (12345, 512, 32, 0.0),
+                                     (96000, 512, 96, 0.05), (8777, 1024, 96, 0.1)])
+def test_streaming_down_projection(ops, dev, M, K, N, p):
+    """ns_gemm_skinny (u = alpha * drop(x) A^T at training size: A^T resident in LDS, x streamed in operand layout with a
+    permuted reduction index): against torch fp32 with the numpy restatement of the keep mask, ragged row counts, the
+    q | k | v width 96, K = 2048 (the fc2 site), a strided destination, and the SAME result as the LDS-staged tile
+    kernel it replaces up to the summation order."""
+    from neuspeech1_amd import lib
+    seed = 424242
+    x = rnd((M, K), dev, 1.0, seed=1)
+    A = rnd((N, K), dev, 0.05, seed=2)
+    keep, inv = _keep_mask(seed, M, K, p, dev) if p > 0 else (torch.ones(M, K, device=dev), 1.0)
+    ldu = N + 8
+    outs = []
+    for mode in (1, 7):
+        lib.load().ns_debug_set_ring(mode)
+        u = torch.full((M, ldu), float("nan"), device=dev, dtype=torch.float16)
+        ops.gemm(A=x, am=ops.rowmap(K), K=K, B=A, ldb=K, M=M, N=N, C16=u, c16m=ops.rowmap(ldu),
+                 flags=ops.NS_GEMM_DROP_A if p > 0 else 0, alpha=inv, drop_p=p, drop_seed=seed)
+        assert torch.isnan(u[:, N:].float()).all() and not torch.isnan(u[:, :N].float()).any()
+        outs.append(u[:, :N].float())
+    lib.load().ns_debug_set_ring(1)
+    ref = (x.float() * keep * inv) @ A.float().T
+    close(outs[0], ref, 1e-2 * (K / 512) ** 0.5, 5e-3, "streaming down-projection")
+    close(outs[0], outs[1], 4e-3 * (K / 512) ** 0.5, 2e-3, "streaming vs tile kernel")
+
+
 @pytest.mark.parametrize("nq,Lk", [(1, 1500), (1, 7), (5, 1500), (3, 130), (8, 33)])
 def test_attn_decode_cross_layout(ops, dev, nq, Lk):
     """ns_attn_decode on a per-group K/V block (cross-attention layout): nq query rows of a group share its Lk keys;

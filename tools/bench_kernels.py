@@ -99,6 +99,13 @@ A2_l = rnd(r, f, scale=0.02)
 u1 = torch.empty(M, r, device=dev, dtype=F16)
 timeit("gemm skinny 96000x32x2048", lambda: ops.gemm(A=gf, am=rowmap(f), K=f, B=A2_l, ldb=f, M=M, N=r, C16=u1, c16m=rowmap(r)),
        2.0 * M * r * f, M * f * 2)
+A1_l = rnd(r, d, scale=0.04)
+timeit("gemm skinny+drop 96000x32x512", lambda: ops.gemm(A=x, am=rowmap(d), K=d, B=A1_l, ldb=d, M=M, N=r, C16=u1, c16m=rowmap(r),
+                                                          flags=ops.NS_GEMM_DROP_A, drop_p=0.05, drop_seed=7),
+       2.0 * M * r * d, M * d * 2)
+timeit("gemm skinny+drop 96000x32x2048", lambda: ops.gemm(A=gf, am=rowmap(f), K=f, B=A2_l, ldb=f, M=M, N=r, C16=u1, c16m=rowmap(r),
+                                                           flags=ops.NS_GEMM_DROP_A, drop_p=0.05, drop_seed=7),
+       2.0 * M * r * f, M * f * 2)
 # conv stem
 T, Cp = 6000, 256
 xin = rnd(B, T + 2, Cp)
