@@ -358,6 +358,8 @@ int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_p8_fits(const ns_gemm_desc* d);
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
+int ns_gemm_tn256_launch(const ns_gemm_desc* d, hipStream_t st);
+bool ns_gemm_tn256_ok(const ns_gemm_desc* d);
 int ns_gemm_skinny_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
@@ -423,7 +425,9 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
   const size_t lds = 2 * TILE_BYTES + 2 * (size_t)bn * BK * 2;   // BN=128: 64 KiB (= the fp32 epilogue tile)
   hipStream_t st = (hipStream_t)stream;
-  if (tn && (g_use_ring || (d->flags & NS_GEMM_COLSUM_A)) && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
+  if (tn && g_use_ring != 0 && g_use_ring != 8 && ns_gemm_tn256_ok(d)) {
+    ns_gemm_tn256_launch(d, st);   // conv-stem weight gradients: 256 x 256 LDS-DMA tiles (mode 8 = off, for A/B runs)
+  } else if (tn && (g_use_ring || (d->flags & NS_GEMM_COLSUM_A)) && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
       d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 && d->M >= 8 && d->N >= 8) {
     ns_gemm_tn_launch(d, st);   // row-major staging + ds_read_b64_tr_b16 fragments
   } else if (tn) {

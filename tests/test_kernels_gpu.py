@@ -211,6 +211,44 @@ def test_gemm_tn_conv_wgrad(ops, dev):
     close(bg, 0.5 + dy.float().sum(0), 2e-3, 1e-3, "bias gradient from the weight-gradient pass")
 
 
+@pytest.mark.parametrize("Bn,T,Cin,Cout,stride", [(9, 4000, 256, 512, 2), (11, 1500, 512, 512, 1), (7, 6000, 256, 256, 2)])
+def test_gemm_tn_conv_wgrad_256_tiles(ops, dev, Bn, T, Cin, Cout, stride):
+    """ns_gemm_tn256 (256 x 256 LDS-DMA tiles, reduction splits chosen by the launcher) on conv-stem weight-gradient shapes:
+    halo row maps of both operands, stride 1 and 2, a reduction length that is not a multiple of the stage depth or of the
+    split count, accumulation onto a non-zero C32, the bias-gradient side output; against conv1d autograd in fp32 and
+    against the 128 x 128 kernel it replaces."""
+    from neuspeech1_amd import lib
+    Tout = T // stride
+    xh = torch.zeros(Bn, T + 2, Cin, device=dev, dtype=torch.float16)
+    xh[:, 1:T + 1] = rnd((Bn, T, Cin), dev, 1.0, seed=1)
+    dy = rnd((Bn * Tout, Cout), dev, 0.5, seed=2)
+    assert Bn * Tout >= 16384 and Bn * Tout % 32 != 0
+    w = torch.zeros(Cout, Cin, 3, device=dev, requires_grad=True)
+    y = F.conv1d(xh[:, 1:T + 1].float().transpose(1, 2), w, None, stride=stride, padding=1)
+    y.backward(dy.float().reshape(Bn, Tout, Cout).transpose(1, 2))
+    ref = w.grad.permute(0, 2, 1).reshape(Cout, 3 * Cin)
+    outs = []
+    for mode in (1, 8):
+        lib.load().ns_debug_set_ring(mode)
+        out = torch.full((Cout, 3 * Cin), 0.25, device=dev, dtype=torch.float32)
+        bg = torch.full((Cout,), 0.5, device=dev)
+        ops.gemm(A=dy, am=ops.rowmap(Cout, Tout, Tout * Cout), K=Bn * Tout, B=xh,
+                 bm=ops.rowmap(stride * Cin, Tout, (T + 2) * Cin), M=Cout, N=3 * Cin, C32=out, ldc32=3 * Cin,
+                 flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32 | ops.NS_GEMM_COLSUM_A, splits=16, H32=bg, alpha=0.5)
+        outs.append((out, bg))
+    lib.load().ns_debug_set_ring(1)
+    scale = (Bn * Tout / 300) ** 0.5
+    close(outs[0][0], 0.25 + 0.5 * ref, 2e-2 * scale, 2e-3, "conv wgrad (256 x 256 tiles)")
+    close(outs[0][1], 0.5 + 0.5 * dy.float().sum(0), 2e-3 * scale, 1e-3, "bias gradient (256 x 256 tiles)")
+    close(outs[0][0], outs[1][0], 2e-3 * scale, 1e-4, "256 x 256 tiles vs 128 x 128 tiles")
+    # plain row maps (no segments)
+    a2, b2 = rnd((20000, 256), dev, 0.5, seed=5), rnd((20000, 512), dev, 0.5, seed=6)
+    c2 = torch.zeros(256, 512, device=dev)
+    ops.gemm(A=a2, am=ops.rowmap(256), K=20000, B=b2, bm=ops.rowmap(512), M=256, N=512, C32=c2, ldc32=512,
+             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=4)
+    close(c2, a2.float().T @ b2.float(), 2e-1, 2e-3, "plain TN through the 256 x 256 tiles")
+
+
 # --------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,d", [(37, 256), (1000, 512), (130, 1280)])
 def test_layernorm(ops, dev, rows, d):

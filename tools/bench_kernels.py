@@ -137,6 +137,20 @@ timeit("tn conv1.0 wgrad 512x768 <- 384000", lambda: ops.gemm(A=pre0, am=rowmap(
                                                                bm=rowmap(Cp, T, (T + 2) * Cp), M=d, N=3 * Cp, C32=gW, ldc32=3 * Cp,
                                                                flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=32),
        2.0 * B * T * d * 3 * Cp)
+# the bench's conv-stem weight gradients ("replace" front end): conv2 512 x 1536 <- 96 000 (stride 2, halo maps), conv1 512 x 768 <- 192 000
+T2w = T // 2
+dp2 = torch.zeros(B, S + 2, d, device=dev, dtype=F16); dp2.normal_()
+g1h = torch.zeros(B, T2w + 2, d, device=dev, dtype=F16); g1h.normal_()
+gW2, gb2 = torch.zeros(d, 3 * d, device=dev, dtype=F32), torch.zeros(d, device=dev, dtype=F32)
+timeit("tn conv2 wgrad 512x1536 <- 96000", lambda: ops.gemm(A=(dp2, d), am=rowmap(d, S, (S + 2) * d), K=B * S, B=g1h,
+                                                             bm=rowmap(2 * d, S, (T2w + 2) * d), M=d, N=3 * d, C32=gW2, ldc32=3 * d,
+                                                             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32 | ops.NS_GEMM_COLSUM_A, H32=gb2,
+                                                             splits=16), 2.0 * B * S * d * 3 * d)
+dp1 = torch.zeros(B, T2w + 2, d, device=dev, dtype=F16); dp1.normal_()
+timeit("tn conv1 wgrad 512x768 <- 192000", lambda: ops.gemm(A=(dp1, d), am=rowmap(d, T2w, (T2w + 2) * d), K=B * T2w, B=xin,
+                                                             bm=rowmap(2 * Cp, T2w, (T + 2) * Cp), M=d, N=3 * Cp, C32=gW, ldc32=3 * Cp,
+                                                             flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32 | ops.NS_GEMM_COLSUM_A, H32=gb2,
+                                                             splits=32), 2.0 * B * T2w * d * 3 * Cp)
 # attention
 ao = torch.empty(M, d, device=dev, dtype=F16)
 lse = torch.empty(B, H, S, device=dev)
