@@ -215,7 +215,8 @@ int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, c
  * LoRA backward, the two products that read dy, in one pass over it (peft lora.Linear backward of
  * y += scale * B (A drop(x)), finetune.py:187-212): for each of the G column groups of dy (q | k | v: G = 3, else 1)
  *   du[:, g*r : (g+1)*r]  = alpha_du * dy_g sB_g           (M x r fp16; sBT[g] = (scale * B_g)^T, r x N fp16, ld = N)
- *   dB[g] (N x lddb fp32) += alpha_db[g] * dy_g^T u_g       (fp32 atomics; u = the forward bottleneck, M x G*r fp16)
+ *   dB[g] (N x lddb fp32) += alpha_db[g] * dy_g^T u_g       (u = the forward bottleneck, M x G*r fp16; summed over the
+ *                                                            workgroups through `workspace` slabs, or by fp32 atomics)
  * dy_g = columns [g*N, (g+1)*N) of dy.  N % 256 == 0, r in {16, 32} (the padded rank), G in {1, 3};
  * ns_lora_bwd_supported() says whether a shape is built (callers keep the two-GEMM path otherwise).
  * `splits` = workgroups (row ranges), 0 = default.
