@@ -21,16 +21,16 @@
 
 namespace {
 
-constexpr int SK_WAVES = 8, SK_NT = 64 * SK_WAVES, SK_DEPTH = 8;   // 8 steps of 64 k in flight per wave
+constexpr int SK_WAVES = 8, SK_NT = 64 * SK_WAVES;   // SK_DEPTH (template): steps of 64 k in flight per wave, 8 (K % 512 == 0) or 4
 typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NTILES, bool DROP>
+template <int NTILES, bool DROP, int SK_DEPTH>
 __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_lds[];
   constexpr int N = 16 * NTILES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int SS = p.K >> 6;                                  // 64-deep steps per row block (multiple of SK_DEPTH)
+  const int SS = p.K >> 6;                                  // 64-deep steps per row block (a multiple of SK_DEPTH)
   const int nblk = (p.M + 15) >> 4;
   const int wstride = gridDim.x * SK_WAVES;
   int rb_l = blockIdx.x * SK_WAVES + wave;                  // row block the load cursor is in
@@ -61,16 +61,17 @@ __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_
   {
     const int pieces = (p.K >> 3) * N;
     const half_t* const Bm = (const half_t*)p.B;
-    // (K / 8) * N is a multiple of 4 * SK_NT for every shape ns_gemm_skinny_ok admits: four loads in flight per thread
+    // four loads in flight per thread
     for (int q0 = tid; q0 < pieces; q0 += 4 * SK_NT) {
       half8 t[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int q = q0 + i * SK_NT, kc = q / N, n = q - kc * N;
+        const int q = min(q0 + i * SK_NT, pieces - 1), kc = q / N, n = q - kc * N;
         t[i] = *(const half8*)(Bm + (long long)n * p.bm.ld + 8 * kc);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *(half8*)(sk_lds + 16 * (q0 + i * SK_NT)) = t[i];
+      for (int i = 0; i < 4; ++i)
+        if (q0 + i * SK_NT < pieces) *(half8*)(sk_lds + 16 * (q0 + i * SK_NT)) = t[i];
     }
   }
   __syncthreads();
@@ -125,37 +126,37 @@ __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_
   }
 }
 
+template <int NTILES, bool DROP, int DEPTH>
+void sk_launch3(const ns_gemm_desc* d, hipStream_t st, int grid, size_t lds) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    hipFuncSetAttribute((const void*)ns_gemm_skinny_kernel<NTILES, DROP, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL((ns_gemm_skinny_kernel<NTILES, DROP, DEPTH>), dim3(grid), dim3(SK_NT), lds, st, *d);
+}
+
 template <int NTILES>
 void sk_launch(const ns_gemm_desc* d, hipStream_t st) {
   const size_t lds = (size_t)d->K * 16 * NTILES * 2;
   const int nblk = (d->M + 15) / 16;
   int grid = (nblk + SK_WAVES - 1) / SK_WAVES;
   if (grid > 256) grid = 256;                               // one workgroup per CU, row blocks strided over its waves
-  static std::once_flag once[2];
   const bool drop = d->drop_p > 0.f && (d->flags & NS_GEMM_DROP_A);
-  if (drop) {
-    std::call_once(once[1], [] {
-      hipFuncSetAttribute((const void*)ns_gemm_skinny_kernel<NTILES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    hipLaunchKernelGGL((ns_gemm_skinny_kernel<NTILES, true>), dim3(grid), dim3(SK_NT), lds, st, *d);
-  } else {
-    std::call_once(once[0], [] {
-      hipFuncSetAttribute((const void*)ns_gemm_skinny_kernel<NTILES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    hipLaunchKernelGGL((ns_gemm_skinny_kernel<NTILES, false>), dim3(grid), dim3(SK_NT), lds, st, *d);
-  }
+  const bool deep = (d->K >> 6) % 8 == 0;
+  if (drop) { if (deep) sk_launch3<NTILES, true, 8>(d, st, grid, lds); else sk_launch3<NTILES, true, 4>(d, st, grid, lds); }
+  else { if (deep) sk_launch3<NTILES, false, 8>(d, st, grid, lds); else sk_launch3<NTILES, false, 4>(d, st, grid, lds); }
 }
 
 }  // namespace
 
-// The shapes this form is built for: plain row-major x and u, N = 32 or 96, K a multiple of 512 with A^T fitting LDS,
+// The shapes this form is built for: plain row-major x and u, N = 32 or 96, K a multiple of 256 with A^T fitting LDS,
 // enough rows that the one-off copy of A^T is amortised; fp16 output only (no bias / residual / second product).
 bool ns_gemm_skinny_ok(const ns_gemm_desc* d) {
   if ((d->flags & ~NS_GEMM_DROP_A) || d->K2 != 0 || d->splits > 1 || d->am.seg_rows != 0 || d->c16m.seg_rows != 0) return false;
   if (!d->C16 || d->G16 || d->H32 || d->C32 || d->bias || d->P16) return false;
   if (d->drop_p > 0.f && !(d->flags & NS_GEMM_DROP_A)) return false;
   if (d->N != 32 && d->N != 96) return false;
-  if (d->K % 512 != 0 || (size_t)d->K * d->N * 2 > 144 * 1024) return false;
+  if (d->K % 256 != 0 || (size_t)d->K * d->N * 2 > 144 * 1024) return false;
   return d->M >= 8192 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 && d->c16m.ld % 4 == 0;
 }
 

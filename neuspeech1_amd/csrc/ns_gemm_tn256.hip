@@ -181,7 +181,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
 bool ns_gemm_tn256_ok(const ns_gemm_desc* d) {
   return (d->flags & NS_GEMM_TN) && (d->flags & NS_GEMM_ATOMIC32) && d->drop_p == 0.f && d->M % 256 == 0 && d->N % 256 == 0 &&
          d->K >= 16384 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 && d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 &&
-         (d->am.seg_rows == 0 || d->am.seg_rows >= 64) && (d->M / 256) * (d->N / 256) <= 64;
+         (d->am.seg_rows == 0 || d->am.seg_rows >= 64) && (d->M / 256) * (d->N / 256) <= 128;
 }
 
 int ns_gemm_tn256_launch(const ns_gemm_desc* d, hipStream_t st) {

@@ -247,6 +247,13 @@ def test_gemm_tn_conv_wgrad_256_tiles(ops, dev, Bn, T, Cin, Cout, stride):
     ops.gemm(A=a2, am=ops.rowmap(256), K=20000, B=b2, bm=ops.rowmap(512), M=256, N=512, C32=c2, ldc32=512,
              flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=4)
     close(c2, a2.float().T @ b2.float(), 2e-1, 2e-3, "plain TN through the 256 x 256 tiles")
+    # large-v2 widths: 5 x 15 tiles, three reduction splits
+    if Cin == 512:
+        a3, b3 = rnd((16500, 1280), dev, 0.5, seed=7), rnd((16500, 3840), dev, 0.5, seed=8)
+        c3 = torch.zeros(1280, 3840, device=dev)
+        ops.gemm(A=a3, am=ops.rowmap(1280), K=16500, B=b3, bm=ops.rowmap(3840), M=1280, N=3840, C32=c3, ldc32=3840,
+                 flags=ops.NS_GEMM_TN | ops.NS_GEMM_ATOMIC32, splits=4)
+        close(c3, a3.float().T @ b3.float(), 2e-1, 2e-3, "75 tiles of 256 x 256")
 
 
 # --------------------------------------------------------------------------- LayerNorm
@@ -476,7 +483,7 @@ def test_lora_dropout_same_mask_in_forward_dgrad_wgrad(ops, dev):
 
 
 @pytest.mark.parametrize("M,K,N,p", [(8200, 512, 32, 0.05), (9001, 512, 96, 0.05), (8192, 2048, 32, 0.05), (12345, 512, 32, 0.0),
-                                     (96000, 512, 96, 0.05), (8777, 1024, 96, 0.1)])
+                                     (96000, 512, 96, 0.05), (8777, 1024, 96, 0.1), (9000, 1280, 32, 0.05), (8200, 768, 96, 0.0)])
 def test_streaming_down_projection(ops, dev, M, K, N, p):
     """ns_gemm_skinny (u = alpha * drop(x) A^T at training size: A^T resident in LDS, x streamed in operand layout with a
     permuted reduction index): against torch fp32 with the numpy restatement of the keep mask, ragged row counts, the
