@@ -13,6 +13,9 @@ from neuspeech1_amd.engine import MegWhisperEngine  # noqa: E402
 from neuspeech1_amd.generate import Generator  # noqa: E402
 from neuspeech1_amd.weights import WhisperDims, make_state_dict, synth_batch  # noqa: E402
 
+if "NS_RING" in os.environ:        # kernel-choice A/B (ns_debug_set_ring, see include/neuspeech_hip.h)
+    from neuspeech1_amd import lib as _l
+    _l.load().ns_debug_set_ring(int(os.environ["NS_RING"]))
 B = int(os.environ.get("B", 128))
 NEW = int(os.environ.get("NEW", 64))
 dev = torch.device("cuda:0")

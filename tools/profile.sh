@@ -2,6 +2,7 @@
 # rocprofv3 evidence for profiles/ (run ON the GPU box through gpurun):
 #   bash tools/profile.sh stats <tag> [bench args]   kernel-trace + stats of bench.py            -> gpurun_out/prof_<tag>/
 #   bash tools/profile.sh pmc   <tag>                 FETCH_SIZE / WRITE_SIZE in SEPARATE passes  -> gpurun_out/pmc_<tag>_*/
+#   bash tools/profile.sh sq    <tag>                 four SQ counters (MFMA busy, LDS) in one pass       -> gpurun_out/pmc_<tag>_SQ/
 #   bash tools/profile.sh decode <tag>                kernel stats of tools/bench_decode.py
 # Counters are collected in runs of their own (never together with --stats / trace domains other than kernel-trace).
 set -u
@@ -19,6 +20,10 @@ case "$mode" in
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_$c.json" 2> "$OUT/pmc_${tag}_$c.log"
     done
     python3 "$ROOT/tools/pmc_summary.py" "$tag"
+    ;;
+  sq)
+    rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_${tag}_SQ" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_SQ.json" 2> "$OUT/pmc_${tag}_SQ.log"
+    python3 "$ROOT/tools/pmc_sq_summary.py" "$tag"
     ;;
   decode)
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/tools/bench_decode.py" "$@" > "$OUT/decode_$tag.log" 2> "$OUT/prof_$tag.log"
