@@ -363,11 +363,7 @@ bool ns_gemm_tn256_ok(const ns_gemm_desc* d);
 int ns_gemm_skinny_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
-static bool ns_lmhead_128 = false;
-extern "C" void ns_debug_set_ring(int on) {
-  ns_lmhead_128 = (on == 9);          // 9 = auto, but 128 x 128 tiles for 512 <= M < 2048 (A/B runs)
-  g_use_ring = on == 9 ? 1 : on;
-}
+extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
 extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   NS_CHECK_ARG(d != nullptr, "ns_gemm: null descriptor");
@@ -450,10 +446,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     // 4 = force the phase-interleaved 256^2 kernel where it applies, 5 = auto without the phase-interleaved kernel
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     const bool big = g_use_ring == 3 || g_use_ring == 4 ||
-                     ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 &&
-                      ((d->M >= 2048 && tiles256 >= 192) || (d->M >= 512 && tiles256 >= 512 && !ns_lmhead_128)));
-    // (second clause: the LM head of a beam-search step, 640 x 51 968 x 512 -- 609 tiles of 256 x 256 move 1.8x fewer
-    // bytes through each CU than 2030 tiles of 128 x 128, and the launch is bound by exactly that)
+                     ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
     const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
