@@ -263,38 +263,81 @@ __global__ __launch_bounds__(256) void adalora_fold_kernel(const float* __restri
 }
 
 // orthogonality regulariser of AdaLoRA: loss += w/num * ||P P^T - I||_F (lora_A, r x in) or ||P^T P - I||_F (lora_B,
-// out x r); adds loss_scale * w/num * 2 (cov - I) P / ||cov - I||_F to the gradient.  One block per matrix, r <= 16.
+// out x r); adds loss_scale * w/num * 2 (cov - I) P / ||cov - I||_F to the gradient.  One block per matrix, r <= 32.
+// Two passes over P in 128-column chunks staged through LDS with coalesced loads (either storage order): pass 1 gives every
+// thread four entries of the r x r Gram matrix, pass 2 gives it 16 rows of one gradient column.  (The first version let each
+// thread walk two strided rows of P in global memory per Gram entry: 2.5 ms per step for the 72 matrices of whisper-base.)
+constexpr int ORTH_CH = 128;
 __global__ __launch_bounds__(256) void orth_reg_kernel(const ns_orth_job* __restrict__ jobs, float weight_over_num,
                                                        const float* __restrict__ loss_scale, float* __restrict__ reg_out) {
   const ns_orth_job j = jobs[blockIdx.x];
   __shared__ float cov[NS_ORTH_MAX_R][NS_ORTH_MAX_R + 1];   // callers keep r <= NS_ORTH_MAX_R (engine / peft_compat check)
-  __shared__ float nrm;
+  __shared__ float tile[NS_ORTH_MAX_R][ORTH_CH + 1];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
   const int r = min(j.r, NS_ORTH_MAX_R), len = j.len;     // P is (r x len) for lora_A [is_b = 0], (len x r) for lora_B [is_b = 1]
   const float* P = j.P;
-  auto at = [&](int k, int t) -> float { return j.is_b ? P[(size_t)t * j.ld + k] : P[(size_t)k * j.ld + t]; };
-  for (int pr = threadIdx.x; pr < r * r; pr += 256) {
-    const int a = pr / r, b = pr % r;
-    float s = 0.f;
-    for (int t = 0; t < len; ++t) s += at(a, t) * at(b, t);
-    cov[a][b] = s - (a == b ? 1.f : 0.f);
+  // tile[k][tt] = P(k, t0 + tt), zero outside the matrix
+  auto stage = [&](int t0) {
+    if (j.is_b) {
+      const int k = tid & 31;
+      for (int tt = tid >> 5; tt < ORTH_CH; tt += 8)
+        tile[k][tt] = (k < r && t0 + tt < len) ? P[(size_t)(t0 + tt) * j.ld + k] : 0.f;
+    } else {
+      const int tt = tid & (ORTH_CH - 1);
+      for (int k = tid >> 7; k < NS_ORTH_MAX_R; k += 2)
+        tile[k][tt] = (k < r && t0 + tt < len) ? P[(size_t)k * j.ld + t0 + tt] : 0.f;
+    }
+  };
+  // ---- pass 1: Gram matrix; thread (a, b0): entries (a, b0 .. b0 + 3)
+  const int a = tid >> 3, b0 = (tid & 7) * 4;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < len; t0 += ORTH_CH) {
+    __syncthreads();
+    stage(t0);
+    __syncthreads();
+#pragma unroll 8
+    for (int tt = 0; tt < ORTH_CH; ++tt) {
+      const float av = tile[a][tt];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] += av * tile[b0 + q][tt];
+    }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int a = 0; a < r; ++a)
-      for (int b = 0; b < r; ++b) s += cov[a][b] * cov[a][b];
-    nrm = sqrtf(s);
-    atomicAdd(reg_out, weight_over_num * nrm);
+  float sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = b0 + q;
+    const float v = (a < r && b < r) ? c[q] - (a == b ? 1.f : 0.f) : 0.f;
+    cov[a][b] = v;
+    sq += v * v;
   }
+  sq = ns_wave_sum(sq);
+  if ((tid & 63) == 0) red[tid >> 6] = sq;
   __syncthreads();
+  const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0) atomicAdd(reg_out, weight_over_num * nrm);
   if (nrm <= 0.f) return;
   const float coef = (loss_scale ? *loss_scale : 1.f) * weight_over_num * 2.f / nrm;
-  for (int i = threadIdx.x; i < r * len; i += 256) {
-    const int k = j.is_b ? i % r : i / len, t = j.is_b ? i / r : i % len;
-    float s = 0.f;
-    for (int b = 0; b < r; ++b) s += cov[k][b] * at(b, t);
-    float* g = j.is_b ? j.G + (size_t)t * j.ld + k : j.G + (size_t)k * j.ld + t;
-    *g += coef * s;
+  // ---- pass 2: G(k, t) += coef * sum_b cov[k][b] P(b, t); thread (column tt, rows 16 kh .. 16 kh + 15)
+  const int tt = tid & (ORTH_CH - 1), kh = tid >> 7;
+  for (int t0 = 0; t0 < len; t0 += ORTH_CH) {
+    __syncthreads();
+    stage(t0);
+    __syncthreads();
+    if (t0 + tt >= len) continue;
+    float pc[NS_ORTH_MAX_R];
+#pragma unroll
+    for (int b = 0; b < NS_ORTH_MAX_R; ++b) pc[b] = tile[b][tt];
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * kh + kk;
+      if (k >= r) break;
+      float sacc = 0.f;
+#pragma unroll
+      for (int b = 0; b < NS_ORTH_MAX_R; ++b) sacc += cov[k][b] * pc[b];
+      float* g = j.is_b ? j.G + (size_t)(t0 + tt) * j.ld + k : j.G + (size_t)k * j.ld + t0 + tt;
+      *g += coef * sacc;
+    }
   }
 }
 

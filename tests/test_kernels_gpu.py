@@ -432,6 +432,41 @@ def test_adamw_clip_scaler(ops, dev):
     close(p, ref_p.detach(), 2e-6, 2e-5, "adamw")
 
 
+def test_orth_reg_value_and_gradient(ops, dev):
+    """ns_orth_reg (AdaLoRA's orthogonality regulariser, peft AdaLoraModel._orthogonal loss: mean over the adapter matrices of
+    ||A A^T - I||_F for lora_A (r x in) and ||B^T B - I||_F for lora_B (out x r)): value and gradient against torch autograd,
+    live ranks below the padded row stride, lengths that are not a multiple of the staging chunk, both storage orders, the
+    loss scale folded into the gradient, accumulation onto a non-zero gradient."""
+    torch.manual_seed(0)
+    cases = [(12, 512, 0), (12, 2048, 0), (32, 512, 0), (16, 300, 0), (12, 512, 1), (32, 2048, 1), (7, 130, 1), (1, 64, 0)]
+    w, scale = 0.5, 1024.0
+    mats, grads, refs, jobs = [], [], [], []
+    for r, n, is_b in cases:
+        rp = 32 if r > 16 else 16
+        if is_b:      # (len x r_pad), live columns [0, r)
+            Pm = torch.zeros(n, rp, device=dev); Pm[:, :r] = torch.randn(n, r, device=dev) * 0.1
+            ld = rp
+        else:         # (r_pad x len), live rows [0, r)
+            Pm = torch.zeros(rp, n, device=dev); Pm[:r] = torch.randn(r, n, device=dev) * 0.1
+            ld = n
+        Gm = torch.full_like(Pm, 0.25)
+        mats.append(Pm); grads.append(Gm)
+        jobs.append((Pm.data_ptr(), Gm.data_ptr(), r, n, ld, is_b))
+        q = Pm.clone().requires_grad_(True)
+        live = q[:, :r] if is_b else q[:r]
+        cov = live.T @ live if is_b else live @ live.T
+        refs.append((q, torch.linalg.norm(cov - torch.eye(r, device=dev))))
+    table, n = ops.make_orth_jobs(jobs, dev)
+    reg = torch.zeros(1, device=dev)
+    ls = torch.tensor([scale], device=dev)
+    ops.orth_reg(table, n, w / n, ls, reg)
+    total = sum(v for _, v in refs) * (w / n)
+    close(reg, total.detach().reshape(1), 1e-5, 1e-4, "orth-reg value")
+    (total * scale).backward()
+    for (q, _), Gm, (r, ln, is_b) in zip(refs, grads, cases):
+        close(Gm, 0.25 + q.grad, 1e-3, 1e-3, f"orth-reg gradient r={r} len={ln} is_b={is_b}")
+
+
 # --------------------------------------------------------------------------- LoRA dropout mask consistency
 def _keep_mask(seed, rows, cols, p, dev):
     """numpy restatement of ns_keep_el (csrc/ns_common.h): one hash per (row, col>>2), one byte per element."""
