@@ -203,13 +203,22 @@ int ns_cast_jobs(const ns_cast_job* jobs_dev, int njobs, void* stream);
  * ---------------------------------------------------------------------- */
 int ns_adalora_fold_grads(const float* dBf, const float* B, const float* E, float* dB, float* dE, int N, int r,
                           float s, void* stream);
+/* the same fold for a table of adapters in one launch; dBf (the scratch gradient of the folded operand) is read, folded
+ * and ZEROED, so a scratch buffer that starts clear stays clear from step to step; r <= 32 */
+typedef struct {
+  float* dBf; const float* B; const float* E; float* dB; float* dE;
+  int32_t N, r; float s;
+} ns_adalora_fold_job;
+int ns_adalora_fold_jobs(const ns_adalora_fold_job* jobs_dev, int njobs, void* stream);
 #define NS_ORTH_MAX_R 32            /* largest live rank ns_orth_reg handles (the reference's init_r is 12) */
 typedef struct {
   const float* P; float* G;       /* parameter and its gradient (same layout) */
   int32_t r, len, ld, is_b;       /* lora_A: (r x len) rows; lora_B: (len x r) with is_b = 1; ld = row stride; r <= NS_ORTH_MAX_R */
 } ns_orth_job;
+/* workspace: ns_orth_reg_workspace_bytes(njobs) bytes (the Gram matrices, summed over the blocks that share a matrix) */
+size_t ns_orth_reg_workspace_bytes(int njobs);
 int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, const float* loss_scale_dev,
-                float* reg_out_dev, void* stream);
+                float* reg_out_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * LoRA backward, the two products that read dy, in one pass over it (peft lora.Linear backward of

@@ -262,52 +262,86 @@ __global__ __launch_bounds__(256) void adalora_fold_kernel(const float* __restri
   if (threadIdx.x < r) atomicAdd(dE + threadIdx.x, acc[threadIdx.x]);
 }
 
+// the same fold for a table of adapters in ONE launch (a layer's six projections: grid = (blocks per job, jobs)); the scratch
+// gradient is zeroed behind the read, so the next backward finds it clear without a fill launch of its own
+__global__ __launch_bounds__(256) void adalora_fold_jobs_kernel(const ns_adalora_fold_job* __restrict__ jobs) {
+  const ns_adalora_fold_job j = jobs[blockIdx.y];
+  __shared__ float acc[32];
+  if (threadIdx.x < 32) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int total = j.N * j.r;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i % j.r;
+    const float g = j.dBf[i];
+    j.dBf[i] = 0.f;
+    j.dB[i] += j.s * j.E[k] * g;
+    atomicAdd(&acc[k], j.s * g * j.B[i]);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < j.r) atomicAdd(j.dE + threadIdx.x, acc[threadIdx.x]);
+}
+
 // orthogonality regulariser of AdaLoRA: loss += w/num * ||P P^T - I||_F (lora_A, r x in) or ||P^T P - I||_F (lora_B,
-// out x r); adds loss_scale * w/num * 2 (cov - I) P / ||cov - I||_F to the gradient.  One block per matrix, r <= 32.
-// Two passes over P in 128-column chunks staged through LDS with coalesced loads (either storage order): pass 1 gives every
-// thread four entries of the r x r Gram matrix, pass 2 gives it 16 rows of one gradient column.  (The first version let each
-// thread walk two strided rows of P in global memory per Gram entry: 2.5 ms per step for the 72 matrices of whisper-base.)
-constexpr int ORTH_CH = 128;
-__global__ __launch_bounds__(256) void orth_reg_kernel(const ns_orth_job* __restrict__ jobs, float weight_over_num,
-                                                       const float* __restrict__ loss_scale, float* __restrict__ reg_out) {
-  const ns_orth_job j = jobs[blockIdx.x];
-  __shared__ float cov[NS_ORTH_MAX_R][NS_ORTH_MAX_R + 1];   // callers keep r <= NS_ORTH_MAX_R (engine / peft_compat check)
-  __shared__ float tile[NS_ORTH_MAX_R][ORTH_CH + 1];
-  __shared__ float red[4];
+// out x r); adds loss_scale * w/num * 2 (cov - I) P / ||cov - I||_F to the gradient; r <= 32.
+// P is walked in 128-column chunks staged through LDS with coalesced loads (either storage order) and read back with 16-B LDS
+// reads.  ORTH_SPLIT blocks share a matrix: the first launch adds each block's partial Gram matrix (four entries per thread)
+// into a zeroed workspace, the second reads the complete matrix, forms the norm and gives each thread 16 gradient rows of one
+// column.  (The first version let each thread walk two strided rows of P in global memory per Gram entry, one block per matrix:
+// 2.5 ms per step for the 72 matrices of whisper-base; one block per matrix with LDS staging: 0.35 ms.)
+constexpr int ORTH_CH = 128, ORTH_LD = ORTH_CH + 4, ORTH_SPLIT = 4;
+
+__device__ __forceinline__ void orth_stage(const ns_orth_job& j, int r, int t0, float (*tile)[ORTH_LD]) {
   const int tid = threadIdx.x;
-  const int r = min(j.r, NS_ORTH_MAX_R), len = j.len;     // P is (r x len) for lora_A [is_b = 0], (len x r) for lora_B [is_b = 1]
-  const float* P = j.P;
-  // tile[k][tt] = P(k, t0 + tt), zero outside the matrix
-  auto stage = [&](int t0) {
-    if (j.is_b) {
-      const int k = tid & 31;
-      for (int tt = tid >> 5; tt < ORTH_CH; tt += 8)
-        tile[k][tt] = (k < r && t0 + tt < len) ? P[(size_t)(t0 + tt) * j.ld + k] : 0.f;
-    } else {
-      const int tt = tid & (ORTH_CH - 1);
-      for (int k = tid >> 7; k < NS_ORTH_MAX_R; k += 2)
-        tile[k][tt] = (k < r && t0 + tt < len) ? P[(size_t)k * j.ld + t0 + tt] : 0.f;
-    }
-  };
-  // ---- pass 1: Gram matrix; thread (a, b0): entries (a, b0 .. b0 + 3)
+  if (j.is_b) {        // (len x r), element (k, t) at P[t * ld + k]
+    const int k = tid & 31;
+    for (int tt = tid >> 5; tt < ORTH_CH; tt += 8)
+      tile[k][tt] = (k < r && t0 + tt < j.len) ? j.P[(size_t)(t0 + tt) * j.ld + k] : 0.f;
+  } else {             // (r x len), element (k, t) at P[k * ld + t]
+    const int tt = tid & (ORTH_CH - 1);
+    for (int k = tid >> 7; k < NS_ORTH_MAX_R; k += 2)
+      tile[k][tt] = (k < r && t0 + tt < j.len) ? j.P[(size_t)k * j.ld + t0 + tt] : 0.f;
+  }
+}
+
+// partial Gram matrices: block (job, s) takes chunks s, s + ORTH_SPLIT, ...; thread (a, b0) owns entries (a, b0 .. b0 + 3)
+__global__ __launch_bounds__(256) void orth_gram_kernel(const ns_orth_job* __restrict__ jobs, float* __restrict__ gram) {
+  const ns_orth_job j = jobs[blockIdx.x];
+  __shared__ __attribute__((aligned(16))) float tile[NS_ORTH_MAX_R][ORTH_LD];
+  const int tid = threadIdx.x, r = min(j.r, NS_ORTH_MAX_R);
   const int a = tid >> 3, b0 = (tid & 7) * 4;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int t0 = 0; t0 < len; t0 += ORTH_CH) {
+  for (int t0 = blockIdx.y * ORTH_CH; t0 < j.len; t0 += ORTH_SPLIT * ORTH_CH) {
     __syncthreads();
-    stage(t0);
+    orth_stage(j, r, t0, tile);
     __syncthreads();
-#pragma unroll 8
-    for (int tt = 0; tt < ORTH_CH; ++tt) {
-      const float av = tile[a][tt];
+#pragma unroll 4
+    for (int tt = 0; tt < ORTH_CH; tt += 4) {
+      const float4 av = *(const float4*)&tile[a][tt];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] += av * tile[b0 + q][tt];
+      for (int q = 0; q < 4; ++q) {
+        const float4 bv = *(const float4*)&tile[b0 + q][tt];
+        c[q] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+      }
     }
   }
-  float sq = 0.f;
+  float* g = gram + (size_t)blockIdx.x * NS_ORTH_MAX_R * NS_ORTH_MAX_R + a * NS_ORTH_MAX_R + b0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int b = b0 + q;
-    const float v = (a < r && b < r) ? c[q] - (a == b ? 1.f : 0.f) : 0.f;
+  for (int q = 0; q < 4; ++q)
+    if (a < r && b0 + q < r) atomicAdd(g + q, c[q]);
+}
+
+__global__ __launch_bounds__(256) void orth_grad_kernel(const ns_orth_job* __restrict__ jobs, const float* __restrict__ gram,
+                                                        float weight_over_num, const float* __restrict__ loss_scale,
+                                                        float* __restrict__ reg_out) {
+  const ns_orth_job j = jobs[blockIdx.x];
+  __shared__ __attribute__((aligned(16))) float cov[NS_ORTH_MAX_R][NS_ORTH_MAX_R + 4];
+  __shared__ __attribute__((aligned(16))) float tile[NS_ORTH_MAX_R][ORTH_LD];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, r = min(j.r, NS_ORTH_MAX_R);
+  float sq = 0.f;
+  for (int i = tid; i < NS_ORTH_MAX_R * NS_ORTH_MAX_R; i += 256) {
+    const int a = i / NS_ORTH_MAX_R, b = i % NS_ORTH_MAX_R;
+    const float v = (a < r && b < r) ? gram[(size_t)blockIdx.x * NS_ORTH_MAX_R * NS_ORTH_MAX_R + i] - (a == b ? 1.f : 0.f) : 0.f;
     cov[a][b] = v;
     sq += v * v;
   }
@@ -315,26 +349,29 @@ __global__ __launch_bounds__(256) void orth_reg_kernel(const ns_orth_job* __rest
   if ((tid & 63) == 0) red[tid >> 6] = sq;
   __syncthreads();
   const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
-  if (tid == 0) atomicAdd(reg_out, weight_over_num * nrm);
+  if (tid == 0 && blockIdx.y == 0) atomicAdd(reg_out, weight_over_num * nrm);
   if (nrm <= 0.f) return;
   const float coef = (loss_scale ? *loss_scale : 1.f) * weight_over_num * 2.f / nrm;
-  // ---- pass 2: G(k, t) += coef * sum_b cov[k][b] P(b, t); thread (column tt, rows 16 kh .. 16 kh + 15)
+  // G(k, t) += coef * sum_b cov[k][b] P(b, t); thread (column tt, rows 16 kh .. 16 kh + 15)
   const int tt = tid & (ORTH_CH - 1), kh = tid >> 7;
-  for (int t0 = 0; t0 < len; t0 += ORTH_CH) {
+  for (int t0 = blockIdx.y * ORTH_CH; t0 < j.len; t0 += ORTH_SPLIT * ORTH_CH) {
     __syncthreads();
-    stage(t0);
+    orth_stage(j, r, t0, tile);
     __syncthreads();
-    if (t0 + tt >= len) continue;
+    if (t0 + tt >= j.len) continue;
     float pc[NS_ORTH_MAX_R];
 #pragma unroll
     for (int b = 0; b < NS_ORTH_MAX_R; ++b) pc[b] = tile[b][tt];
-#pragma unroll 4
+#pragma unroll 2
     for (int kk = 0; kk < 16; ++kk) {
       const int k = 16 * kh + kk;
       if (k >= r) break;
       float sacc = 0.f;
 #pragma unroll
-      for (int b = 0; b < NS_ORTH_MAX_R; ++b) sacc += cov[k][b] * pc[b];
+      for (int b = 0; b < NS_ORTH_MAX_R; b += 4) {
+        const float4 cv = *(const float4*)&cov[k][b];
+        sacc += cv.x * pc[b] + cv.y * pc[b + 1] + cv.z * pc[b + 2] + cv.w * pc[b + 3];
+      }
       float* g = j.is_b ? j.G + (size_t)(t0 + tt) * j.ld + k : j.G + (size_t)k * j.ld + t0 + tt;
       *g += coef * sacc;
     }
@@ -422,11 +459,28 @@ extern "C" int ns_adalora_fold_grads(const float* dBf, const float* B, const flo
   return NS_OK;
 }
 
+extern "C" int ns_adalora_fold_jobs(const ns_adalora_fold_job* jobs_dev, int njobs, void* stream) {
+  NS_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "ns_adalora_fold_jobs: bad arguments");
+  hipLaunchKernelGGL(adalora_fold_jobs_kernel, dim3(16, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  NS_CHECK_LAUNCH("ns_adalora_fold_jobs");
+  return NS_OK;
+}
+
+extern "C" size_t ns_orth_reg_workspace_bytes(int njobs) { return (size_t)njobs * NS_ORTH_MAX_R * NS_ORTH_MAX_R * sizeof(float); }
+
 extern "C" int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_over_num, const float* loss_scale_dev,
-                           float* reg_out_dev, void* stream) {
+                           float* reg_out_dev, void* workspace, size_t workspace_bytes, void* stream) {
   NS_CHECK_ARG(jobs_dev && njobs > 0 && reg_out_dev, "ns_orth_reg: bad arguments");
-  hipLaunchKernelGGL(orth_reg_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, weight_over_num, loss_scale_dev,
-                     reg_out_dev);
+  NS_CHECK_ARG(workspace && workspace_bytes >= ns_orth_reg_workspace_bytes(njobs),
+               "ns_orth_reg: workspace of %zu bytes is smaller than ns_orth_reg_workspace_bytes(%d)", workspace_bytes, njobs);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, ns_orth_reg_workspace_bytes(njobs), st) != hipSuccess) {
+    ns_set_error("ns_orth_reg: hipMemsetAsync failed");
+    return NS_ERR_HIP;
+  }
+  hipLaunchKernelGGL(orth_gram_kernel, dim3(njobs, ORTH_SPLIT), dim3(256), 0, st, jobs_dev, (float*)workspace);
+  hipLaunchKernelGGL(orth_grad_kernel, dim3(njobs, ORTH_SPLIT), dim3(256), 0, st, jobs_dev, (const float*)workspace, weight_over_num,
+                     loss_scale_dev, reg_out_dev);
   NS_CHECK_LAUNCH("ns_orth_reg");
   return NS_OK;
 }

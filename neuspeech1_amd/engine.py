@@ -377,6 +377,27 @@ class MegWhisperEngine:
                         oj.append((pp(ad["site"] + ".lora_A") + 4 * j * r * kin, gp(ad["site"] + ".lora_A") + 4 * j * r * kin, rr, kin, kin, 0))
                         oj.append((pp(pj + ".lora_B"), gp(pj + ".lora_B"), rr, nout, r, 1))
             self._orth_table, self._n_orth = ops.make_orth_jobs(oj, self.dev)
+            # fused adapter backward: the folded operands' gradients of one layer land in ONE scratch buffer (q | k | v, out,
+            # fc1, fc2 at fixed offsets) and a single ns_adalora_fold_jobs launch per layer turns them into dB / dE and
+            # clears the scratch again (36 fold launches + 24 fills per step before)
+            self._ada_off = {"qkv": 0, "out": 3 * d * r, "fc1": 4 * d * r, "fc2": (4 * d + f) * r}
+            self._ada_scr = torch.zeros((5 * d + f) * r, device=self.dev, dtype=F32)
+            self._fold_tables = []
+            sc_, qs_ = self.lora.scale, 64 ** -0.5
+            pa = lambda name, off=0: self.P.data_ptr() + 4 * (self.seg_off[name][0] + off)  # noqa: E731
+            ga = lambda name, off=0: self.G.data_ptr() + 4 * (self.seg_off[name][0] + off)  # noqa: E731
+            for i in range(self.n_lora):
+                p = f"model.encoder.layers.{i}."
+                fj = []
+                for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                    k = p + f"self_attn.{nm}.lora_B"
+                    fj.append((self._ada_scr.data_ptr() + 4 * (self._ada_off["qkv"] + j * d * r), pa(k), pa(p + "self_attn.qkv.lora_E", j * r),
+                               ga(k), ga(p + "self_attn.qkv.lora_E", j * r), d, r, sc_ * qs_ if j == 0 else sc_))
+                for nm, slot, no in (("self_attn.out_proj", "out", d), ("fc1", "fc1", f), ("fc2", "fc2", d)):
+                    k = p + nm
+                    fj.append((self._ada_scr.data_ptr() + 4 * self._ada_off[slot], pa(k + ".lora_B"), pa(k + ".lora_E"), ga(k + ".lora_B"),
+                               ga(k + ".lora_E"), no, r, sc_))
+                self._fold_tables.append(ops.make_fold_jobs(fj, self.dev))
             self.reg_dev = torch.zeros(1, device=self.dev)
             self._gbf = torch.zeros(max(d, f) * r, device=self.dev, dtype=F32)
             self._gbf3 = torch.zeros(max(3 * d, f) * r, device=self.dev, dtype=F32)
@@ -823,13 +844,13 @@ class MegWhisperEngine:
             if r:
                 # fc2: du = dy*sB / keep ; dB = s*dy^T u ; dA = du^T mask(gf) ; dgf = dy*W + mask * (du*A)
                 # (the kernels apply the dropout MASK only: 1/keep rides in du's alpha, forward in u's alpha)
-                self._lora_du_db(dy, d, d, M, b["u2"][i], b["du"], [lo["fc2_sBT"]], [p + "fc2"], [sc])
+                self._lora_du_db(dy, d, d, M, b["u2"][i], b["du"], [lo["fc2_sBT"]], [p + "fc2"], [sc], ada_slot="fc2")
                 self._with_seed(seed + 3, lambda: self._wgrad(b["du"], r, b["gf"][i], f, M, r, f, p + "fc2.lora_A", drop=True))
                 self._with_seed(seed + 3, lambda: self._dgrad(dy, M, Lw["fc2"], b["dpre_f"], P16=b["pre_f"][i], A2=b["du"],
                                                                lda2=r, K2=r, B2=lo["fc2_AT"], drop=True))
                 # fc1
                 dpf = b["dpre_f"]
-                self._lora_du_db(dpf, f, f, M, b["u1"][i], b["du"], [lo["fc1_sBT"]], [p + "fc1"], [sc])
+                self._lora_du_db(dpf, f, f, M, b["u1"][i], b["du"], [lo["fc1_sBT"]], [p + "fc1"], [sc], ada_slot="fc1")
                 self._with_seed(seed + 2, lambda: self._wgrad(b["du"], r, b["x2"][i], d, M, r, d, p + "fc1.lora_A", drop=True))
                 self._with_seed(seed + 2, lambda: self._dgrad(dpf, M, Lw["fc1"], b["dx16"], A2=b["du"], lda2=r, K2=r,
                                                                B2=lo["fc1_AT"], drop=True))
@@ -839,7 +860,7 @@ class MegWhisperEngine:
             ops.layernorm_bwd(b["dx16"], False, hmid, *b["st2"][i], Lw["ln2"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
             dy = b["dh16"]
             if r:
-                self._lora_du_db(dy, d, d, M, b["uo"][i], b["du"], [lo["out_sBT"]], [p + "self_attn.out_proj"], [sc])
+                self._lora_du_db(dy, d, d, M, b["uo"][i], b["du"], [lo["out_sBT"]], [p + "self_attn.out_proj"], [sc], ada_slot="out")
                 self._with_seed(seed + 1, lambda: self._wgrad(b["du"], r, b["ao"][i], d, M, r, d,
                                                                p + "self_attn.out_proj.lora_A", drop=True))
                 self._with_seed(seed + 1, lambda: self._dgrad(dy, M, Lw["out"], b["dao"], A2=b["du"], lda2=r, K2=r,
@@ -853,7 +874,7 @@ class MegWhisperEngine:
             if r:
                 self._lora_du_db(dqkv, 3 * d, d, M, b["uqkv"][i], b["du3"], [lo["sBqT"], lo["sBkT"], lo["sBvT"]],
                                  [p + f"self_attn.{nm}" for nm in ("q_proj", "k_proj", "v_proj")], [sc * qs, sc, sc],
-                                 enames=[(p + "self_attn.qkv.lora_E", j * r) for j in range(3)])
+                                 enames=[(p + "self_attn.qkv.lora_E", j * r) for j in range(3)], ada_slot="qkv")
                 self._with_seed(seed, lambda: self._wgrad(b["du3"], 3 * r, b["x1"][i], d, M, 3 * r, d,
                                                            p + "self_attn.qkv.lora_A", drop=True))
                 self._with_seed(seed, lambda: self._dgrad(dqkv, M, Lw["qkv"], b["dx16"], A2=b["du3"], lda2=3 * r, K2=3 * r,
@@ -861,6 +882,8 @@ class MegWhisperEngine:
             else:
                 self._dgrad(dqkv, M, Lw["qkv"], b["dx16"])
             ops.layernorm_bwd(b["dx16"], False, hin, *b["st1"][i], Lw["ln1"][0], b["dh32"], b["dh32"], b["dh16"], M, d)
+            if r and self.adalora:
+                ops.adalora_fold_jobs(*self._fold_tables[i])     # dB / dE of this layer's six projections, scratch cleared
             if on_ready is not None and r and i in (nl // 2, 0):
                 # adapter gradients of layers [i, hi_l] are final: two chunks (upper half, lower half of the adapted layers)
                 hi_l = nl - 1 if (i == nl // 2 and i != 0) or nl // 2 == 0 else nl // 2 - 1
@@ -892,7 +915,7 @@ class MegWhisperEngine:
         ops.adalora_fold_grads(tmp, self.pview(key + ".lora_B"), (self.pview(en), eoff), self.gview(key + ".lora_B"),
                                (self.gview(en), eoff), N, r, s)
 
-    def _lora_du_db(self, dy16, ldy, N, M, u16, du16, sBT, keys, alphas, enames=None):
+    def _lora_du_db(self, dy16, ldy, N, M, u16, du16, sBT, keys, alphas, enames=None, ada_slot=None):
         """Backward of the adapter up-projections of ONE site (G = len(keys) column groups of dy: q | k | v, else one):
         du_g = dy_g sB_g / keep and dB_g = s dy_g^T u_g.  One fused pass over dy (ns_lora_bwd_dudb) where the shape is
         built, else the skinny GEMM + weight-gradient GEMM pair.  AdaLoRA: the product lands in a scratch buffer and
@@ -901,7 +924,13 @@ class MegWhisperEngine:
         # (fused vs the two GEMMs at M = 96 000, profiles/r2_b: q | k | v 131 vs 153 us, out / fc2 44 vs 51 us, fc1 165 vs 176 us;
         # its dB partials leave by fp32 atomics, N x r x 4 B per workgroup, which is what keeps the N = 2048 site close)
         if ops.lora_bwd_supported(N, r, G) and not self.no_fused_lora_bwd:
-            if self.adalora:
+            if self.adalora and ada_slot is not None:
+                # the layer's scratch (clear: ns_adalora_fold_jobs zeroes what it folds); folded once per layer by the caller
+                o = self._ada_off[ada_slot]
+                tmp = self._ada_scr[o:o + G * N * r].view(G, N * r)
+                dB = [tmp[g] for g in range(G)]
+                al = [1.0] * G
+            elif self.adalora:
                 tmp = self._gbf3[:G * N * r].view(G, N * r)
                 tmp.zero_()
                 dB = [tmp[g] for g in range(G)]
@@ -911,7 +940,7 @@ class MegWhisperEngine:
                 al = list(alphas)
             ops.lora_bwd_dudb(dy=dy16, ldy=ldy, u=u16, ldu=G * r, du=du16, lddu=G * r, sBT=sBT, dB=dB, lddb=r, M=M, N=N, r=r,
                               alpha_du=self._drop_inv(), alpha_db=al)
-            if self.adalora:
+            if self.adalora and ada_slot is None:
                 for g, k in enumerate(keys):
                     en, eoff = enames[g] if enames else (k + ".lora_E", 0)
                     ops.adalora_fold_grads(tmp[g], self.pview(k + ".lora_B"), (self.pview(en), eoff), self.gview(k + ".lora_B"),

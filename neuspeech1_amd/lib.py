@@ -57,6 +57,11 @@ class OrthJob(C.Structure):
                 ("is_b", C.c_int32)]
 
 
+class AdaloraFoldJob(C.Structure):
+    _fields_ = [("dBf", C.c_void_p), ("B", C.c_void_p), ("E", C.c_void_p), ("dB", C.c_void_p), ("dE", C.c_void_p),
+                ("N", C.c_int32), ("r", C.c_int32), ("s", C.c_float)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
@@ -166,7 +171,9 @@ SIGNATURES = {
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
+    "ns_adalora_fold_jobs": (C.c_int, [_vp, _i, _vp]),
+    "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ns_orth_reg_workspace_bytes": (_sz, [_i]),
     "ns_lora_bwd_supported": (C.c_int, [_i, _i, _i]),
     "ns_lora_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ns_lora_bwd_dudb": (C.c_int, [C.POINTER(LoraBwdDesc), _vp]),

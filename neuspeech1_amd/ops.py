@@ -268,6 +268,18 @@ def adalora_fold_grads(dBf, B, E, dB, dE, N, r, s):
             "ns_adalora_fold_grads")
 
 
+def make_fold_jobs(jobs, device):
+    """jobs: list of (dBf_ptr, B_ptr, E_ptr, dB_ptr, dE_ptr, N, r, s)"""
+    arr = (L.AdaloraFoldJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i] = L.AdaloraFoldJob(*j)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(jobs)
+
+
+def adalora_fold_jobs(table, njobs):
+    L.check(L.load().ns_adalora_fold_jobs(ptr(table), njobs, _stream()), "ns_adalora_fold_jobs")
+
+
 def make_orth_jobs(jobs, device):
     """jobs: list of (P_ptr, G_ptr, r, len, ld, is_b)"""
     arr = (L.OrthJob * len(jobs))()
@@ -276,9 +288,17 @@ def make_orth_jobs(jobs, device):
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(jobs)
 
 
+_orth_ws = {}
+
+
 def orth_reg(table, njobs, weight_over_num, loss_scale_dev, reg_out_dev):
-    L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), _stream()),
-            "ns_orth_reg")
+    need = L.load().ns_orth_reg_workspace_bytes(njobs)
+    ws = _orth_ws.get(reg_out_dev.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=reg_out_dev.device, dtype=torch.uint8)
+        _orth_ws[reg_out_dev.device] = ws
+    L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), ptr(ws), ws.numel(),
+                                 _stream()), "ns_orth_reg")
 
 
 # ----------------------------------------------------------------------------- LoRA backward (du + dB in one pass over dy)
