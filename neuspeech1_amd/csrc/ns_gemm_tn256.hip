@@ -80,6 +80,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
   int seg[2], within[2];
   const half_t* srcA[2];
   const half_t* srcB[2];
+  bool colB[2];                     // the last column tile may be ragged (N % 8 == 0): chunks past N come from the block of zeros
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = 4 * wave + 2 * i + lh, k = k_begin + rl;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
     const int cl = (lr ^ rl) & 31;
     srcA[i] = (const half_t*)p.A + i0 + cl * 8;
     srcB[i] = (const half_t*)p.B + j0 + cl * 8;
+    colB[i] = j0 + cl * 8 < p.N;
   }
   auto issue = [&](int step) __attribute__((always_inline)) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (step & (T_NST - 1)) * T_STAGE_BYTES + wave * 2048);
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
         ob = (long long)within[i] * p.bm.ld;
       }
       t_glds16(ok ? (const void*)(srcA[i] + oa) : (const void*)ns_t256_zero_chunk, dst + i * 1024);
-      t_glds16(ok ? (const void*)(srcB[i] + ob) : (const void*)ns_t256_zero_chunk, dst + T_OP_BYTES + i * 1024);
+      t_glds16(ok && colB[i] ? (const void*)(srcB[i] + ob) : (const void*)ns_t256_zero_chunk, dst + T_OP_BYTES + i * 1024);
       within[i] += T_BK;
       if (p.am.seg_rows > 0 && within[i] >= p.am.seg_rows) { within[i] -= p.am.seg_rows; seg[i] += 1; }
     }
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      if (j0 + wj * 64 + b * 32 + lr >= p.N) continue;
       float* const dst = p.C32 + (long long)(i0 + wi * 128 + a * 32 + 4 * lh) * p.ldc32 + j0 + wj * 64 + b * 32 + lr;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -177,15 +180,15 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
 
 }  // namespace
 
-// Whole 256 x 256 tiles, a long reduction, no dropout mask, fp32 atomics into C32 (the caller zeroes it, as for every split TN call)
+// Whole 256-row tiles of the output (M % 256 == 0), column tiles may end ragged (N % 8 == 0), a long reduction, no dropout mask, fp32 atomics into C32 (the caller zeroes it, as for every split TN call)
 bool ns_gemm_tn256_ok(const ns_gemm_desc* d) {
-  return (d->flags & NS_GEMM_TN) && (d->flags & NS_GEMM_ATOMIC32) && d->drop_p == 0.f && d->M % 256 == 0 && d->N % 256 == 0 &&
+  return (d->flags & NS_GEMM_TN) && (d->flags & NS_GEMM_ATOMIC32) && d->drop_p == 0.f && d->M % 256 == 0 && d->N % 8 == 0 && d->N >= 256 &&
          d->K >= 16384 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 && d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 &&
-         (d->am.seg_rows == 0 || d->am.seg_rows >= 64) && (d->M / 256) * (d->N / 256) <= 128;
+         (d->am.seg_rows == 0 || d->am.seg_rows >= 64) && (d->M / 256) * ((d->N + 255) / 256) <= 128;
 }
 
 int ns_gemm_tn256_launch(const ns_gemm_desc* d, hipStream_t st) {
-  const int tiles_j = d->N / 256, tiles = (d->M / 256) * tiles_j;
+  const int tiles_j = (d->N + 255) / 256, tiles = (d->M / 256) * tiles_j;
   // one workgroup per CU (128 KiB of LDS): as many reduction splits as fill the 256 CUs once
   int splits = 256 / tiles;
   if (splits < 1) splits = 1;

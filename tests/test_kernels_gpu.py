@@ -211,7 +211,8 @@ def test_gemm_tn_conv_wgrad(ops, dev):
     close(bg, 0.5 + dy.float().sum(0), 2e-3, 1e-3, "bias gradient from the weight-gradient pass")
 
 
-@pytest.mark.parametrize("Bn,T,Cin,Cout,stride", [(9, 4000, 256, 512, 2), (11, 1500, 512, 512, 1), (7, 6000, 256, 256, 2)])
+@pytest.mark.parametrize("Bn,T,Cin,Cout,stride", [(9, 4000, 256, 512, 2), (11, 1500, 512, 512, 1), (7, 6000, 256, 256, 2),
+                                                  (5, 6004, 320, 512, 1)])   # 273 channels padded to 320: N = 960, a ragged last tile
 def test_gemm_tn_conv_wgrad_256_tiles(ops, dev, Bn, T, Cin, Cout, stride):
     """ns_gemm_tn256 (256 x 256 LDS-DMA tiles, reduction splits chosen by the launcher) on conv-stem weight-gradient shapes:
     halo row maps of both operands, stride 1 and 2, a reduction length that is not a multiple of the stage depth or of the

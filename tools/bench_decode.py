@@ -26,7 +26,10 @@ x, labels = synth_batch(dims, B, 1234)
 x = torch.from_numpy(x).to(dev)
 prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
 ONLY = os.environ.get("BEAMS")     # "1" or "5": one mode only (clean rocprofv3 kernel stats per mode)
-for nb, kw in ((1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
+SB = {}
+if os.environ.get("SB"):           # evaluation.py --add_sequence_bias: a small table of single- and multi-token entries
+    SB = dict(sequence_bias={(7,): 2.0, (11, 12): 1.5, (20, 21, 22): 3.0, (300,): -1.0, (41, 42): 0.5})
+for nb, kw in ((1, dict(SB)), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2, **SB))):
     if ONLY and int(ONLY) != nb:
         continue
     for it in range(2):
