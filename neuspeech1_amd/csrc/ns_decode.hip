@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) void topk_stage2_kernel(const float* __restric
 constexpr int SEL_MAX_LDV = 26 * 256 * 8;   // bitmap capacity (53,248 columns)
 constexpr int SEL_CAP = 1024;               // candidate / patch list capacity
 constexpr int SEL_WORDS = SEL_MAX_LDV / 32;
+constexpr int SEL_NV = SEL_MAX_LDV / 8 / 256;   // 16-B vectors of a row per thread (26)
 
 __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc_desc p, int k, int group_rows,
                                                             float* __restrict__ cand_vals, int* __restrict__ cand_idx) {
@@ -513,6 +514,8 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
   __shared__ float sh[4], shv[4];
   __shared__ int shi[4];
   __shared__ int npatch, ncand;
+  __shared__ float tmax[256];
+  __shared__ float Tsh;
   const int row = blockIdx.x, tid = threadIdx.x;
   const half_t* lg = (const half_t*)p.logits16 + (long long)row * p.ldv;
   const int64_t* ids = p.ids + (long long)row * p.ids_ld;
@@ -532,27 +535,40 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
       return;
     }
   }
+  // The row (<= 53,248 fp16 logits) is read ONCE into registers, every load in flight together: each of the four passes
+  // below used to walk global memory again with four 16-B loads in flight per thread, i.e. a latency-bound 8-10 us per
+  // pass and row (79 us per beam-search step for 640 rows).
+  half8 rowv[SEL_NV];
+#pragma unroll
+  for (int u = 0; u < SEL_NV; ++u) {
+    const int vi = tid + u * 256;
+    rowv[u] = *(const half8*)(lg + (long long)min(vi, nvec - 1) * 8);
+  }
   for (int i = tid; i < SEL_WORDS; i += 256) { ovr[i] = 0u; inf[i] = 0u; }
   if (tid == 0) { npatch = 0; ncand = 0; }
 
   float lse = 0.f;
   if (p.log_softmax) {
     float mx = -INFINITY;
-#pragma unroll 4
-    for (int vi = tid; vi < nvec; vi += 256) {
-      const half8 v = *(const half8*)(lg + (long long)vi * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (vi * 8 + e < V) mx = fmaxf(mx, (float)v[e]);
+    for (int u = 0; u < SEL_NV; ++u) {
+      const int vi = tid + u * 256;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (vi * 8 + e < V) mx = fmaxf(mx, (float)rowv[u][e]);
+      }
     }
     mx = blk_reduce(mx, true, sh);
     float se = 0.f;
-#pragma unroll 4
-    for (int vi = tid; vi < nvec; vi += 256) {
-      const half8 v = *(const half8*)(lg + (long long)vi * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (vi * 8 + e < V) se += __expf((float)v[e] - mx);
+    for (int u = 0; u < SEL_NV; ++u) {
+      const int vi = tid + u * 256;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (vi * 8 + e < V) se += __expf((float)rowv[u][e] - mx);
+      }
     }
     se = blk_reduce(se, false, sh);
     lse = mx + __logf(se);
@@ -596,36 +612,45 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
 
   // ---- per-thread maximum of the un-overridden columns, T = k-th largest of the 256 maxima
   float mloc = -INFINITY;
-#pragma unroll 4
-  for (int vi = tid; vi < nvec; vi += 256) {
-    const half8 v = *(const half8*)(lg + (long long)vi * 8);
-    const int c0 = vi * 8;
-    const uint32_t m8 = (ovr[c0 >> 5] >> (c0 & 31)) & 0xFFu;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (c0 + e < V && !((m8 >> e) & 1u)) mloc = fmaxf(mloc, (float)v[e]);
+  for (int u = 0; u < SEL_NV; ++u) {
+    const int vi = tid + u * 256;
+    if (vi < nvec) {
+      const int c0 = vi * 8;
+      const uint32_t m8 = (ovr[c0 >> 5] >> (c0 & 31)) & 0xFFu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e < V && !((m8 >> e) & 1u)) mloc = fmaxf(mloc, (float)rowv[u][e]);
+    }
   }
+  // (by RANK: every thread counts the maxima ahead of its own -- value desc, thread index asc -- and the one at rank k - 1
+  // publishes its value; k rounds of block-wide argmax cost ~1.2 us each, 20 of them per row with the final selection)
   float T = -INFINITY;
   {
-    float mine = mloc;
-    for (int t = 0; t < k; ++t) {
-      float bv = mine;
-      int bi = tid;
-      blk_argmax_after(bv, bi, shv, shi);
-      T = bv;
-      if (bi == tid) mine = -INFINITY;
-      __syncthreads();
+    tmax[tid] = mloc;
+    if (tid == 0) Tsh = -INFINITY;
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int jj = 0; jj < 256; ++jj) {
+      const float vj = tmax[jj];
+      rank += (vj > mloc || (vj == mloc && jj < tid)) ? 1 : 0;
     }
+    if (rank == k - 1) Tsh = mloc;
+    __syncthreads();
+    T = Tsh;
   }
   // ---- candidates: raw >= T (un-overridden) + finite patch entries, in final-value space
   if (mloc >= T && mloc > -INFINITY) {     // threads whose maximum is below T hold no candidate: skip their re-read
-    for (int vi = tid; vi < nvec; vi += 256) {
-      const half8 v = *(const half8*)(lg + (long long)vi * 8);
+#pragma unroll
+    for (int u = 0; u < SEL_NV; ++u) {
+      const int vi = tid + u * 256;
+      if (vi >= nvec) continue;
       const int c0 = vi * 8;
       const uint32_t m8 = (ovr[c0 >> 5] >> (c0 & 31)) & 0xFFu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float raw = (float)v[e];
+        const float raw = (float)rowv[u][e];
         if (c0 + e < V && !((m8 >> e) & 1u) && raw >= T) {
           const int pos = atomicAdd(&ncand, 1);
           if (pos < SEL_CAP) { ccol[pos] = c0 + e; cval[pos] = finalv(raw); }
@@ -645,19 +670,33 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
   const bool overflow = ncand > SEL_CAP || npatch > SEL_CAP;
   const int nc = min(ncand, SEL_CAP);
   const int gbase = (row % group_rows) * V;
+  if (!overflow) {
+    // the short candidate list, by rank as well (value desc, column asc; columns are unique): candidate i lands at its rank
+    for (int i = tid; i < nc; i += 256) {
+      const float v = cval[i];
+      const int c = ccol[i];
+      int rank = 0;
+      for (int jj = 0; jj < nc; ++jj) {
+        const float vj = cval[jj];
+        rank += (vj > v || (vj == v && ccol[jj] < c)) ? 1 : 0;
+      }
+      if (rank < k) {
+        cand_vals[(long long)row * k + rank] = v;
+        cand_idx[(long long)row * k + rank] = gbase + c;
+      }
+    }
+    if (tid >= nc && tid < k) {          // fewer candidates than k: the rest as an exhausted argmax reports them
+      cand_vals[(long long)row * k + tid] = -INFINITY;
+      cand_idx[(long long)row * k + tid] = 0x7fffffff;
+    }
+    return;
+  }
   float pv = INFINITY;
   int pi = -1;
   for (int t = 0; t < k; ++t) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    if (!overflow) {
-      for (int i = tid; i < nc; i += 256) {
-        const float v = cval[i];
-        const int c = ccol[i];
-        const bool after = (v < pv) || (v == pv && c > pi);
-        if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
-      }
-    } else {
+    {
       // lists overflowed (pathological rows: hundreds of ties, or a prompt longer than the list): exact slow path,
       // k full passes over the row in final-value space
 #pragma unroll 1
