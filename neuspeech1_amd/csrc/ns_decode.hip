@@ -474,6 +474,24 @@ __global__ __launch_bounds__(256) void topk_stage2_kernel(const float* __restric
   __shared__ int shi[4];
   const float* v = cv + (long long)blockIdx.x * ncand;
   const int* id = ci + (long long)blockIdx.x * ncand;
+  if (ncand <= 1024 && k <= 256) {
+    // short lists (the beam step: num_beams x 2 num_beams candidates): every candidate counts the ones ahead of it (value
+    // desc, index asc) and lands at its rank; k rounds of block-wide argmax cost ~1.2 us each
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    for (int i = threadIdx.x; i < ncand; i += 256) { sv[i] = v[i]; si[i] = id[i]; }
+    if ((int)threadIdx.x < k) { vals[blockIdx.x * k + threadIdx.x] = -INFINITY; idx[blockIdx.x * k + threadIdx.x] = 0x7fffffff; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncand; i += 256) {
+      const float x = sv[i];
+      const int gi = si[i];
+      if (!(x > -INFINITY) && gi == 0x7fffffff) continue;       // padding entries: what the defaults already say
+      int rank = 0;
+      for (int jj = 0; jj < ncand; ++jj) rank += (sv[jj] > x || (sv[jj] == x && si[jj] < gi)) ? 1 : 0;
+      if (rank < k) { vals[blockIdx.x * k + rank] = x; idx[blockIdx.x * k + rank] = gi; }
+    }
+    return;
+  }
   float pv = INFINITY;
   int pi = -1;
   for (int t = 0; t < k; ++t) {
@@ -729,13 +747,25 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const ns_beam_desc p) 
   __shared__ int run_src[MAXQ], run_tok[MAXQ], fin_src[MAXQ], c_beam[2 * MAXQ], c_tok[2 * MAXQ];
   __shared__ float run_sc[MAXQ], fin_sc[MAXQ];
   __shared__ unsigned char fin_dn[MAXQ], c_hit[2 * MAXQ];
-  const float* tv = p.top_vals + (long long)b * K2;
-  const int* ti = p.top_idx + (long long)b * K2;
+  // the inputs of the serial section below come in through LDS, fetched by 3 nb lanes at once (thread 0 used to issue its
+  // ~25 dependent global loads one after the other: most of the kernel's 25 us)
+  __shared__ float runc[2 * MAXQ], finc[3 * MAXQ];     // LDS, not lane-private arrays: dynamically indexed private arrays live in scratch
+  __shared__ unsigned char done_m[3 * MAXQ];
+  __shared__ float tv[2 * MAXQ], fin_in[MAXQ];
+  __shared__ int ti[2 * MAXQ];
+  __shared__ unsigned char fdn_in[MAXQ];
+  if ((int)threadIdx.x < K2) {
+    tv[threadIdx.x] = p.top_vals[(long long)b * K2 + threadIdx.x];
+    ti[threadIdx.x] = p.top_idx[(long long)b * K2 + threadIdx.x];
+  } else if ((int)threadIdx.x < K2 + nb) {
+    const int i = threadIdx.x - K2;
+    fin_in[i] = p.fin_scores_in[b * nb + i];
+    fdn_in[i] = p.fin_done_in[b * nb + i];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const bool open = p.open[b] != 0;
     const float lenf = powf((float)(cur + 1 - p.prompt_len), p.length_penalty);
-    float runc[2 * MAXQ], finc[3 * MAXQ];
-    unsigned char done_m[3 * MAXQ];
     bool all_hit = true;
     for (int c = 0; c < K2; ++c) {
       c_beam[c] = ti[c] / p.V;
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const ns_beam_desc p) 
       finc[nb + c] = f;
       done_m[nb + c] = just;
     }
-    for (int i = 0; i < nb; ++i) { finc[i] = p.fin_scores_in[b * nb + i]; done_m[i] = p.fin_done_in[b * nb + i]; }
+    for (int i = 0; i < nb; ++i) { finc[i] = fin_in[i]; done_m[i] = fdn_in[i]; }
     // next running beams: best nb of runc (value desc, index asc)
     unsigned used = 0;
     for (int r = 0; r < nb; ++r) {
@@ -781,19 +811,23 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const ns_beam_desc p) 
     if (!all_hit) atomicOr(p.any_continuation, 1);
   }
   __syncthreads();
-  for (int r = 0; r < nb; ++r) {
-    const int64_t* src = p.run_seqs_in + ((long long)b * nb + c_beam[run_src[r]]) * ML;
-    int64_t* dst = p.run_seqs_out + ((long long)b * nb + r) * ML;
-    for (int t = threadIdx.x; t < ML; t += 256) dst[t] = (t == cur) ? (int64_t)run_tok[r] : src[t];
-    const int fs = fin_src[r];
-    int64_t* fdst = p.fin_seqs_out + ((long long)b * nb + r) * ML;
-    if (fs < nb) {
-      const int64_t* fsrc = p.fin_seqs_in + ((long long)b * nb + fs) * ML;
-      for (int t = threadIdx.x; t < ML; t += 256) fdst[t] = fsrc[t];
+  // the 2 nb sequence rows of this batch item, all (row, position) pairs in one flat loop: every load is independent (one loop per
+  // row waited for a global round trip per row)
+  for (int e = threadIdx.x; e < 2 * nb * ML; e += 256) {
+    const int rr = e / ML, t = e - rr * ML;
+    if (rr < nb) {
+      const int r = rr;
+      const int64_t* src = p.run_seqs_in + ((long long)b * nb + c_beam[run_src[r]]) * ML;
+      p.run_seqs_out[((long long)b * nb + r) * ML + t] = (t == cur) ? (int64_t)run_tok[r] : src[t];
     } else {
-      const int c = fs - nb;
-      const int64_t* fsrc = p.run_seqs_in + ((long long)b * nb + c_beam[c]) * ML;
-      for (int t = threadIdx.x; t < ML; t += 256) fdst[t] = (t == cur) ? (int64_t)c_tok[c] : fsrc[t];
+      const int r = rr - nb, fs = fin_src[r];
+      int64_t v;
+      if (fs < nb) v = p.fin_seqs_in[((long long)b * nb + fs) * ML + t];
+      else {
+        const int c = fs - nb;
+        v = (t == cur) ? (int64_t)c_tok[c] : p.run_seqs_in[((long long)b * nb + c_beam[c]) * ML + t];
+      }
+      p.fin_seqs_out[((long long)b * nb + r) * ML + t] = v;
     }
   }
   if (threadIdx.x < nb) {
