@@ -238,6 +238,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     qf[s] = *(const half8*)(Q + (long long)qrow * p.ldq + 16 * s + 8 * lh);
+#ifndef NS_ATTN_NO_LOG2
+    // log2(e) rides on the query fragment (used for S only; dQ = dS K reads K): S' = S log2(e) comes out of the MFMA and the
+    // probability is exp2(S' - lse log2(e)) with no multiply per score (32 of the ~190 VALU issue slots per tile and lane)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)((float)qf[s][j] * LOG2E);
+#endif
     dof[s] = *(const half8*)(dO + (long long)qrow * p.lddo + 16 * s + 8 * lh);
     const half8 of = *(const half8*)(O + (long long)qrow * p.ldo + 16 * s + 8 * lh);
 #pragma unroll
@@ -272,7 +278,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
+#ifndef NS_ATTN_NO_LOG2
+      for (int r = 0; r < 16; ++r) { st[kt][r] = -lse * LOG2E; dp[kt][r] = -delta; }
+#else
       for (int r = 0; r < 16; ++r) { st[kt][r] = -lse; dp[kt][r] = -delta; }
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 ak = *(const half8*)(Ks + lds_off(kt * 32 + lr, 2 * s + lh));
@@ -295,7 +305,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
+#ifndef NS_ATTN_NO_LOG2
+      for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]) * dp[kt][r];   // dS^T
+#else
       for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] * LOG2E) * dp[kt][r];   // dS^T
+#endif
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -351,6 +365,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
   for (int s = 0; s < 4; ++s) {
     kf[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
     vf[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
+#ifndef NS_ATTN_NO_LOG2
+    // log2(e) rides on the key fragment (used for S only; dK = dS^T Q reads Q from LDS), see attn_bwd_dq_kernel
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kf[s][j] = (half_t)((float)kf[s][j] * LOG2E);
+#endif
   }
   f32x16 dkt[2], dvt[2];
 #pragma unroll
@@ -376,7 +395,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
     // -lse / -delta of the tile's 64 queries; queries past Lq get -inf so their probabilities vanish without a mask
     if (threadIdx.x < 64) {
       const bool qok = q0 + (int)threadIdx.x < p.Lq;
+#ifndef NS_ATTN_NO_LOG2
+      lse_s[threadIdx.x] = qok ? -lse_r * LOG2E : -INFINITY;
+#else
       lse_s[threadIdx.x] = qok ? -lse_r : -INFINITY;
+#endif
       del_s[threadIdx.x] = -del_r;
     }
     __syncthreads();
@@ -414,7 +437,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifndef NS_ATTN_NO_LOG2
+        const float pv = __builtin_amdgcn_exp2f(st[qt][r]);
+#else
         const float pv = __builtin_amdgcn_exp2f(st[qt][r] * LOG2E);
+#endif
         st[qt][r] = pv;                 // P
         dp[qt][r] = pv * dp[qt][r];     // dS
       }

@@ -125,7 +125,6 @@ class Generator:
         qkv = torch.empty(Bp, 3 * d, device=dev, dtype=F16)
         qc = torch.empty(Bp, d, device=dev, dtype=F16)
         ao = torch.empty(Bp, d, device=dev, dtype=F16)
-        pre = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
         gf = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
         st = (torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
         logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
@@ -167,7 +166,7 @@ class Generator:
                                     ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
                 eng._lin(ao, Bp, Lw["cout"], R32=h[1], H32=h[0])
                 ops.layernorm_fwd(h[0], *Lw["ln3"], x16, *st, Bp, d)
-                eng._lin(x16, Bp, Lw["fc1"], C16=pre, G16=gf, gelu=True)
+                eng._lin(x16, Bp, Lw["fc1"], G16=gf, gelu=True)     # (no pre-activation copy: nothing reads it without a backward)
                 eng._lin(gf, Bp, Lw["fc2"], R32=h[0], H32=h[1])
                 h.reverse()
             ops.layernorm_fwd(h[0], *eng.dec_ln, x16, *st, Bp, d)
