@@ -523,6 +523,7 @@ constexpr int SEL_MAX_LDV = 26 * 256 * 8;   // bitmap capacity (53,248 columns)
 constexpr int SEL_CAP = 1024;               // candidate / patch list capacity
 constexpr int SEL_WORDS = SEL_MAX_LDV / 32;
 constexpr int SEL_NV = SEL_MAX_LDV / 8 / 256;   // 16-B vectors of a row per thread (26)
+constexpr int SEL_MATCH = 256;                  // matched multi-token sequence-bias entries per row (more: exact slow path)
 
 __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc_desc p, int k, int group_rows,
                                                             float* __restrict__ cand_vals, int* __restrict__ cand_idx) {
@@ -534,6 +535,10 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
   __shared__ int npatch, ncand;
   __shared__ float tmax[256];
   __shared__ float Tsh;
+  __shared__ uint32_t hist[SEL_WORDS];       // sequence-bias mode: tokens of the row's history (for the repetition penalty)
+  __shared__ int mlast[SEL_MATCH];           // ... and the matched multi-token entries (last token, bias)
+  __shared__ float mbias[SEL_MATCH];
+  __shared__ int nmatch;
   const int row = blockIdx.x, tid = threadIdx.x;
   const half_t* lg = (const half_t*)p.logits16 + (long long)row * p.ldv;
   const int64_t* ids = p.ids + (long long)row * p.ids_ld;
@@ -562,8 +567,9 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
     const int vi = tid + u * 256;
     rowv[u] = *(const half8*)(lg + (long long)min(vi, nvec - 1) * 8);
   }
-  for (int i = tid; i < SEL_WORDS; i += 256) { ovr[i] = 0u; inf[i] = 0u; }
-  if (tid == 0) { npatch = 0; ncand = 0; }
+  const bool biased = p.bias1 != nullptr || p.n_seq > 0;
+  for (int i = tid; i < SEL_WORDS; i += 256) { ovr[i] = 0u; inf[i] = 0u; if (biased) hist[i] = 0u; }
+  if (tid == 0) { npatch = 0; ncand = 0; nmatch = 0; }
 
   float lse = 0.f;
   if (p.log_softmax) {
@@ -599,7 +605,50 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
     return o;
   };
   // ---- processors -> bitmaps + patch list (same order / semantics as logits_process_kernel)
-  if (p.repetition_penalty != 1.f) {
+  if (biased) {
+    // HF order: sequence bias first, the repetition penalty then works on the BIASED score.  Every column one of the two
+    // touches gets ONE patch: ((raw - lse) + bias1[c]) + the matched multi-token entries ending in c, then the penalty if
+    // c occurs in the history.  Columns nothing touches keep (raw - lse) + 0.0 = raw - lse, i.e. the unbiased path.
+    auto touch = [&](int c) __attribute__((always_inline)) {
+      const uint32_t bit = 1u << (c & 31);
+      if (!(atomicOr(&ovr[c >> 5], bit) & bit)) {
+        const int pos = atomicAdd(&npatch, 1);
+        if (pos < SEL_CAP) { pcol[pos] = c; pval[pos] = ((float)lg[c] - lse) + (p.bias1 ? p.bias1[c] : 0.f); }
+      }
+    };
+    if (p.repetition_penalty != 1.f)
+      for (int t = tid; t < cur; t += 256) {
+        const int64_t tok = ids[t];
+        if (tok >= 0 && tok < V) { atomicOr(&hist[tok >> 5], 1u << (tok & 31)); touch((int)tok); }
+      }
+    if (p.bias1)
+      for (int c = tid; c < V; c += 256)
+        if (p.bias1[c] != 0.f) touch(c);
+    for (int sq = tid; sq < p.n_seq; sq += 256) {
+      const int o0 = p.seq_off[sq], len = p.seq_off[sq + 1] - o0, pre = len - 1;
+      if (pre < 1 || len > cur) continue;      // HF ignores sequences longer than the context
+      bool match = true;
+      for (int e = 0; e < pre; ++e) match = match && (ids[cur - pre + e] == (int64_t)p.seq_tok[o0 + e]);
+      const int last = p.seq_tok[o0 + pre];
+      if (match && last >= 0 && last < V) {
+        touch(last);
+        const int mp = atomicAdd(&nmatch, 1);
+        if (mp < SEL_MATCH) { mlast[mp] = last; mbias[mp] = p.seq_bias[sq]; }
+      }
+    }
+    __syncthreads();
+    const int np0 = min(npatch, SEL_CAP), nm = min(nmatch, SEL_MATCH);
+    for (int i = tid; i < nm; i += 256)
+      for (int q = 0; q < np0; ++q)
+        if (pcol[q] == mlast[i]) { atomicAdd(&pval[q], mbias[i]); break; }
+    __syncthreads();
+    if (p.repetition_penalty != 1.f)
+      for (int q = tid; q < np0; q += 256) {
+        const int c = pcol[q];
+        if ((hist[c >> 5] >> (c & 31)) & 1u) { const float b = pval[q]; pval[q] = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty; }
+      }
+    __syncthreads();
+  } else if (p.repetition_penalty != 1.f) {
     for (int t = tid; t < cur; t += 256) {
       const int64_t tok = ids[t];
       if (tok >= 0 && tok < V) {
@@ -685,7 +734,7 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
     }
   }
   __syncthreads();
-  const bool overflow = ncand > SEL_CAP || npatch > SEL_CAP;
+  const bool overflow = ncand > SEL_CAP || npatch > SEL_CAP || nmatch > SEL_MATCH;
   const int nc = min(ncand, SEL_CAP);
   const int gbase = (row % group_rows) * V;
   if (!overflow) {
@@ -722,8 +771,20 @@ __global__ __launch_bounds__(256) void logits_select_kernel(const ns_logits_proc
         float v;
         if ((inf[c >> 5] >> (c & 31)) & 1u) v = -INFINITY;
         else if ((ovr[c >> 5] >> (c & 31)) & 1u) {
-          const float b = (float)lg[c] - lse;
-          v = b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty;
+          float b = (float)lg[c] - lse;
+          bool pen = true;
+          if (biased) {     // rebuild the patch value of this column from the tables (order of the adds as in logits_process_kernel)
+            b += p.bias1 ? p.bias1[c] : 0.f;
+            for (int sq = 0; sq < p.n_seq; ++sq) {
+              const int o0 = p.seq_off[sq], len = p.seq_off[sq + 1] - o0, pre = len - 1;
+              if (pre < 1 || len > cur || p.seq_tok[o0 + pre] != c) continue;
+              bool match = true;
+              for (int e = 0; e < pre; ++e) match = match && (ids[cur - pre + e] == (int64_t)p.seq_tok[o0 + e]);
+              if (match) b += p.seq_bias[sq];
+            }
+            pen = (hist[c >> 5] >> (c & 31)) & 1u;
+          }
+          v = (pen && p.repetition_penalty != 1.f) ? (b < 0.f ? b * p.repetition_penalty : b / p.repetition_penalty) : b;
           if (p.beam_scores) v += bs;
         } else v = finalv((float)lg[c]);
         const bool after = (v < pv) || (v == pv && c > pi);
@@ -965,7 +1026,7 @@ extern "C" int ns_logits_select(const ns_logits_proc_desc* d, int k, int group_r
                "ns_logits_select: ldv=%d must be a multiple of 8 and <= %d (use ns_logits_process + ns_topk_groups beyond)",
                d->ldv, SEL_MAX_LDV);
   NS_CHECK_ARG(k >= 1 && k <= 16 && group_rows >= 1 && d->cur_len >= 0 && d->cur_len <= d->ids_ld, "ns_logits_select: bad shape");
-  NS_CHECK_ARG(!d->bias1 && d->n_seq == 0, "ns_logits_select: sequence bias needs ns_logits_process + ns_topk_groups");
+  NS_CHECK_ARG(d->n_seq == 0 || (d->seq_tok && d->seq_off && d->seq_bias), "ns_logits_select: sequence-bias tables missing");
   NS_CHECK_ARG(d->n_suppress == 0 || d->suppress, "ns_logits_select: suppress list missing");
   NS_CHECK_ARG(d->n_begin_suppress == 0 || d->begin_suppress, "ns_logits_select: begin_suppress list missing");
   hipLaunchKernelGGL(logits_select_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)stream, *d, k, group_rows, cand_vals, cand_idx);

@@ -14,6 +14,8 @@ Design notes (MI355X-first):
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -130,7 +132,7 @@ class Generator:
         logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
         sb = _sequence_bias_tables(sequence_bias, V, dev)   # HF SequenceBiasLogitsProcessor (model.generate(sequence_bias=...))
         # processors + per-row top-k in one pass, no fp32 score matrix (a sequence bias takes the two-kernel form)
-        fused_select = Vp <= ops.SELECT_MAX_LDV and not sb
+        fused_select = Vp <= ops.SELECT_MAX_LDV and os.environ.get("NS_NO_FUSED_SELECT") != "1"
         scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
 
         def step(tok: torch.Tensor, t: int, parent, ctr=None):

@@ -218,9 +218,11 @@ SELECT_MAX_LDV = 26 * 256 * 8
 
 def logits_select(*, logits16, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, k, group_rows, cand_vals,
                   cand_idx, beam_scores=None, repetition_penalty=1.0, no_repeat_ngram=0, suppress=None, n_suppress=0,
-                  begin_suppress=None, n_begin_suppress=0, cur_len_dev=None, scores32=None, forced=None, n_forced=0):
+                  begin_suppress=None, n_begin_suppress=0, cur_len_dev=None, scores32=None, forced=None, n_forced=0,
+                  bias1=None, seq_tok=None, seq_off=None, seq_bias=None, n_seq=0):
     d = L.LogitsProcDesc()
     d.forced, d.n_forced = ptr(forced), n_forced
+    d.bias1, d.seq_tok, d.seq_off, d.seq_bias, d.n_seq = ptr(bias1), ptr(seq_tok), ptr(seq_off), ptr(seq_bias), n_seq
     d.logits16, d.scores32, d.ids, d.beam_scores = ptr(logits16), None, ptr(ids), ptr(beam_scores)
     d.suppress, d.begin_suppress, d.cur_len_dev = ptr(suppress), ptr(begin_suppress), ptr(cur_len_dev)
     d.rows, d.V, d.ldv, d.ids_ld, d.cur_len, d.begin_index = rows, V, ldv, ids_ld, cur_len, begin_index

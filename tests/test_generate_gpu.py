@@ -131,7 +131,8 @@ def test_processors_and_topk_kernels(dev):
 
 
 @pytest.mark.parametrize("V,ldv,case", [(1000, 1024, "plain"), (51865, 51968, "plain"), (51865, 51968, "ties"),
-                                        (51865, 51968, "clustered")])
+                                        (51865, 51968, "clustered"), (1000, 1024, "biased"), (51865, 51968, "biased"),
+                                        (51865, 51968, "biased-clustered")])
 def test_fused_select_is_bit_identical_to_process_plus_topk(dev, V, ldv, case):
     """ns_logits_select + ns_topk_merge == ns_logits_process + ns_topk_groups: same values, same flat indices, same
     order, including rows full of ties (fp16 logits) and rows whose top values sit in ONE thread's columns (the
@@ -143,7 +144,7 @@ def test_fused_select_is_bit_identical_to_process_plus_topk(dev, V, ldv, case):
     logits = torch.zeros(rows, ldv, device=dev, dtype=torch.float16)
     if case == "ties":
         logits[:, :V] = torch.randint(-4, 5, (rows, V), device=dev).half()           # nine distinct values
-    elif case == "clustered":
+    elif case.endswith("clustered"):
         logits[:, :V] = (torch.randn(rows, V, device=dev)).half()
         cols = (torch.arange(0, 24, device=dev)[:, None] * 2048 + torch.arange(0, 8, device=dev)[None, :]).reshape(-1) + 8 * 7
         logits[:, cols[cols < V]] = (20 + torch.arange(0, (cols < V).sum(), device=dev) * 0.125).half()   # all in thread 7
@@ -157,6 +158,17 @@ def test_fused_select_is_bit_identical_to_process_plus_topk(dev, V, ldv, case):
     sup = torch.tensor([5, 6, int(logits[4, :V].float().argmax())], device=dev, dtype=torch.int32)
     common = dict(logits16=logits, ids=ids, rows=rows, V=V, ldv=ldv, ids_ld=L, cur_len=cur, begin_index=cur,
                   repetition_penalty=5.0, no_repeat_ngram=2, suppress=sup, n_suppress=3, begin_suppress=sup, n_begin_suppress=1)
+    if case.startswith("biased"):
+        # sequence bias (HF SequenceBiasLogitsProcessor, evaluation.py --add_sequence_bias): single tokens (one of them in the
+        # history, one the row leader, one suppressed), multi-token entries whose prefix ends row 1's / row 3's history (two of
+        # them sharing their last token with a single-token entry), one longer than the context, one that does not match
+        from neuspeech1_amd.generate import _sequence_bias_tables
+        lead3 = int(logits[3, :V].float().argmax())
+        h1, h3 = [int(t) for t in ids[1, cur - 2:cur]], [int(t) for t in ids[3, cur - 1:cur]]
+        sb = {(7,): 4.0, (int(ids[2, 5]),): -3.0, (lead3,): 2.5, (5,): 9.0, (V - 1,): 6.0,
+              (h1[0], h1[1], 11): 8.0, (h1[1], 11): 1.5, (h3[0], 7): 3.0, (h3[0], V - 2): 12.0,
+              tuple(range(1, cur + 3)): 5.0, (V - 3, V - 4, 12): 7.0}
+        common.update(_sequence_bias_tables(sb, V, dev))
     for lsm, beams in ((True, bs), (False, None)):
         scores = torch.empty(rows, V, device=dev)
         ops.logits_process(scores32=scores, log_softmax=lsm, beam_scores=beams, **common)
