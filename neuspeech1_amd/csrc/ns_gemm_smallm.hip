@@ -116,6 +116,11 @@ __global__ __launch_bounds__(SM_NT) void ns_gemm_smallm_kernel(const ns_gemm_des
 // Beyond ~384 tiles the 32 x 32 form is bound by operand traffic (every tile re-reads 32 rows of each operand at the
 // ~42 GB/s a CU can fetch): measured slower than the 128 x 32 LDS-staged tile there (tools/probe/smallm_ab.py).
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d) {
+  // (N = 32 with M > 1024 -- the du products of the decoder's adapters under --ft_full -- also comes here: 88 tiles of 32 x 32
+  // instead of 22 tiles of 128 x 32)
+  if (!(d->flags & NS_GEMM_TN) && d->K2 == 0 && d->drop_p == 0.f && d->am.seg_rows == 0 && d->N == 32 && d->M > NS_SM_MAXM &&
+      d->M <= 8192 && d->K >= 256 && d->K <= 4096)
+    return true;
   if ((d->flags & NS_GEMM_TN) || d->K2 != 0 || d->drop_p != 0.f || d->am.seg_rows != 0 || d->M > NS_SM_MAXM || d->N < 64 ||
       d->N > 4096 || d->K < 256)
     return false;

@@ -572,7 +572,9 @@ class MegWhisperEngine:
         # blocks in flight: ~1.5 per CU for the 128 x 32 tiles of dB (more splits only add atomics: 23 us at 384 blocks,
         # 30 us at 768 for N = 512), ~3 per CU for the others (tools/probe/tn_splits.py)
         target = 384 if (Ko <= 96 or 32 < No <= 128) else 768
-        splits = max(1, min(Mred // 256, (target + tiles - 1) // tiles))
+        # (short reductions -- the decoder's adapters under --ft_full, 2816 rows -- split down to one 64-row step per workgroup:
+        # with 256-row ranges a 32 x 512 gradient ran on 44 workgroups of four dependent steps each, 29 us)
+        splits = max(1, min(Mred // (256 if Mred >= 16384 else 64), (target + tiles - 1) // tiles))
         bptr = self.G.data_ptr() + 4 * self.seg_off[bias_gname][0] if bias_gname else None
         ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
                  ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32 | (NS_GEMM_COLSUM_A if bias_gname else 0), splits=splits,
