@@ -116,9 +116,21 @@ typedef struct {
      survivors' 256/(256-thr8) belongs in the caller's alpha (of the down-projection / of the GEMM producing A2). */
   float drop_p; uint32_t drop_seed;
   float alpha;              /* acc is multiplied by alpha first (0 is read as 1) */
+  /* Side product of a GELU epilogue (the LoRA down-projection of the NEXT Linear, peft lora.Linear.forward of fc2:
+     u = A drop(gelu(fc1 x)), finetune.py:205-212): if side_B != NULL the kernel also forms, per 256-column output tile t,
+       side_out[t][m][j] = sum_{n in tile t} mask(side_drop_seed, m, n) * G16[m][n] * side_B[j][n]      (fp32, j < side_n = 32)
+     from the fp16 GELU values it has just staged, so the (M x N) GELU output is not read again for it.  side_out holds
+     (N / 256) slabs of (M x 32) floats; ns_gemm_side_reduce sums them, scales and rounds to fp16.  Only on the large-M path
+     (ns_gemm_side_supported), with NS_GEMM_GELU and G16; N % 256 == 0.  The mask is the LoRA-dropout keep mask (mask only). */
+  const void* side_B; int32_t side_ldb, side_n;
+  float* side_out;
+  float side_drop_p; uint32_t side_drop_seed;
 } ns_gemm_desc;
 
 int ns_gemm(const ns_gemm_desc* d, void* stream);
+int ns_gemm_side_supported(int M, int N, int K);
+/* u16[m][j] = round16(alpha * sum_t slabs[t][m][j]),  t < tiles, j < 32 */
+int ns_gemm_side_reduce(const float* slabs, int tiles, int M, float alpha, void* u16, int ldu, void* stream);
 /* A/B knob for benchmarks: 1 (default) = automatic kernel choice, 0 = register-staged kernel only; 2..5 force one of
  * the wide NT kernels (see ns_gemm.hip), 6 = automatic without the small-M split-K kernel */
 void ns_debug_set_ring(int on);

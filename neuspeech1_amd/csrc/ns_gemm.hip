@@ -365,6 +365,40 @@ bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
+// the shapes the phase-interleaved 256 x 256 kernel takes in automatic mode, with whole 256-column tiles
+extern "C" int ns_gemm_side_supported(int M, int N, int K) {
+  const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  return N >= 256 && N % 256 == 0 && M >= 2048 && tiles256 >= 192 && K % 16 == 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void side_reduce_kernel(const float* __restrict__ slabs, int tiles, int M, float alpha,
+                                                          half_t* __restrict__ u16, int ldu) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // float4 index inside a slab
+  if (q >= (long long)M * 8) return;
+  const long long per = (long long)M * 8;
+  const float4* src = (const float4*)slabs + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < tiles; ++t) {
+    const float4 x = src[(long long)t * per];
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+  }
+  const long long m = q >> 3;
+  const int j = (int)(q & 7) * 4;
+  const half4 o = {(half_t)(a.x * alpha), (half_t)(a.y * alpha), (half_t)(a.z * alpha), (half_t)(a.w * alpha)};
+  *(half4*)(u16 + m * ldu + j) = o;
+}
+}  // namespace
+
+extern "C" int ns_gemm_side_reduce(const float* slabs, int tiles, int M, float alpha, void* u16, int ldu, void* stream) {
+  NS_CHECK_ARG(slabs && u16 && tiles > 0 && M > 0 && ldu >= 32 && ldu % 4 == 0, "ns_gemm_side_reduce: bad arguments");
+  const long long n = (long long)M * 8;
+  hipLaunchKernelGGL(side_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, tiles, M,
+                     alpha == 0.f ? 1.f : alpha, (half_t*)u16, ldu);
+  NS_CHECK_LAUNCH("ns_gemm_side_reduce");
+  return NS_OK;
+}
+
 extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   NS_CHECK_ARG(d != nullptr, "ns_gemm: null descriptor");
   NS_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "ns_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -412,6 +446,13 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                    "ns_gemm(TN): COLSUM_A needs H32 and the 128 x 128 transposed-read kernel (M, N > 96, strides multiples of 8)");
   }
   NS_CHECK_ARG(tn || !(d->flags & NS_GEMM_COLSUM_A), "ns_gemm: COLSUM_A is a TN-only side output");
+  if (d->side_B) {
+    NS_CHECK_ARG(!tn && d->side_out && d->side_n == 32 && d->side_ldb % 8 == 0 && d->side_ldb >= d->N && (d->flags & NS_GEMM_GELU) &&
+                     d->G16 && !d->H32 && !(d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) && d->splits <= 1 &&
+                     ns_gemm_side_supported(d->M, d->N, d->K) && g_use_ring == 1,
+                 "ns_gemm: side product needs the large-M GELU form (ns_gemm_side_supported, G16, side_n = 32, side_out)");
+    NS_CHECK_ARG(d->side_drop_p >= 0.f && d->side_drop_p <= 0.5f, "ns_gemm: side_drop_p out of range (0 .. 0.5)");
+  }
   if (d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) NS_CHECK_ARG(d->P16, "ns_gemm: DGELU / MUL_P16 need P16");
   NS_CHECK_ARG(!(d->flags & NS_GEMM_GELU_SAVE_GRAD) || (d->flags & NS_GEMM_GELU), "ns_gemm: GELU_SAVE_GRAD needs GELU");
   NS_CHECK_ARG(d->drop_p >= 0.f && d->drop_p <= 0.5f, "ns_gemm: drop_p out of range (0 .. 0.5)");

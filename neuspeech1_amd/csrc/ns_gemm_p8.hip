@@ -33,7 +33,8 @@ constexpr int BUF = 4 * REGION;              // 64 KiB
 constexpr int RA0 = 0, RA1 = 1, RB0 = 2, RB1 = 3;
 constexpr int LDH = BN * 2 + 16;             // epilogue: bytes per staged fp16 row
 constexpr int EPI_BYTES = BM * LDH;          // 132 KiB
-constexpr int LDS_BYTES = EPI_BYTES > 2 * BUF ? EPI_BYTES : 2 * BUF;
+constexpr int SIDE_BYTES = 32 * 256 * 2;     // side product: the 32 x 256 slice of side_B of this tile's columns (16 KiB, behind the staged tile)
+constexpr int LDS_BYTES = (EPI_BYTES > 2 * BUF ? EPI_BYTES : 2 * BUF) + SIDE_BYTES;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     const half_t* const P16 = (const half_t*)p.P16;
     const bool do_gelu = p.flags & NS_GEMM_GELU;
     const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
+    const uint32_t side_thr = (KIND == NS_EPI_PLAIN && p.side_B && p.side_drop_p > 0.f) ? ns_drop_thr8(p.side_drop_p) : 0u;
     f32x4 res[KIND == NS_EPI_RES ? 16 : 1][2];
     half8 pre[KIND == NS_EPI_DGELU ? 16 : 1];
     auto prefetch = [&](int i0) __attribute__((always_inline)) {
@@ -418,9 +420,24 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
         }
       }
     };
+    // side product: this tile's 32 x 256 slice of side_B goes to LDS ONCE per workgroup (each wave fetching its own fragments
+    // from global memory cost 2048 64-B requests per tile, ~12 k cycles); 16-B chunk c of row j sits at chunk c ^ (j & 15)
+    char* const sbs = smem + (EPI_BYTES > 2 * BUF ? EPI_BYTES : 2 * BUF);
+    uint4 sb0 = make_uint4(0, 0, 0, 0), sb1 = sb0;
+    const bool side = KIND == NS_EPI_PLAIN && p.side_B != nullptr;
+    if (side) {
+      const half_t* const SB = (const half_t*)p.side_B + n0 + (tid & 31) * 8;
+      sb0 = *(const uint4*)(SB + (long long)(tid >> 5) * p.side_ldb);
+      sb1 = *(const uint4*)(SB + (long long)(16 + (tid >> 5)) * p.side_ldb);
+    }
     prefetch(0);
     stage_tile();
     prefetch(8);
+    if (side) {
+      const int j = tid >> 5, c = tid & 31;
+      *(uint4*)(sbs + j * 512 + ((c ^ (j & 15)) << 4)) = sb0;
+      *(uint4*)(sbs + (16 + j) * 512 + ((c ^ (j & 15)) << 4)) = sb1;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     NS_P8_BARRIER();
     NS_STAMP(4);
@@ -456,6 +473,18 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
         }
         if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = cv;
         if (G16) *(half8*)(G16 + ns_rm_off64(p.g16m, row) + ecol) = gv;
+        if (KIND == NS_EPI_PLAIN && p.side_B) {
+          // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged tile,
+          // LoRA-dropout mask applied, for the MFMA pass below
+          uint4 w = __builtin_bit_cast(uint4, gv);
+          if (side_thr) {
+            uint32_t mk[4];
+            ns_keep_masks(ns_drop_word(p.side_drop_seed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
+            ns_keep_masks(ns_drop_word(p.side_drop_seed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
+            w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
+          }
+          *(uint4*)(hs + rl * LDH + ecg * 16) = w;
+        }
         if (KIND == NS_EPI_RES) {
           f32x4 h0 = res[i][0], h1 = res[i][1];
 #pragma unroll
@@ -467,6 +496,36 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
       }
     }
     NS_STAMP(6);
+    if (KIND == NS_EPI_PLAIN && p.side_B) {
+      // side_out[tn][m][j] = sum_n gm[m][n] side_B[j][n0 + n] over this tile's 256 columns: wave w takes rows 32 w .. 32 w + 31
+      // (two 16-row tiles) x 32 adapter rows (two 16-row tiles) x 8 steps of 32 columns; side_B on the MFMA A port, so a lane
+      // owns 4 consecutive j of one output row (one 16-B store)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NS_P8_BARRIER();
+      half8 sbf[2][8];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ss = 0; ss < 8; ++ss)
+          sbf[jt][ss] = *(const half8*)(sbs + (16 * jt + l15) * 512 + (((4 * ss + lg) ^ l15) << 4));
+      float* const slab = p.side_out + ((long long)tn * p.M) * 32;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rl = 32 * wave + 16 * mt + l15;
+        f32x4 su[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ss = 0; ss < 8; ++ss) {
+          const half8 gm = *(const half8*)(hs + rl * LDH + (32 * ss + 8 * lg) * 2);
+          su[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sbf[0][ss], gm, su[0], 0, 0, 0);
+          su[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sbf[1][ss], gm, su[1], 0, 0, 0);
+        }
+        const int row = m0 + rl;
+        if (row < p.M) {
+          *(f32x4*)(slab + (long long)row * 32 + 4 * lg) = su[0];
+          *(f32x4*)(slab + (long long)row * 32 + 16 + 4 * lg) = su[1];
+        }
+      }
+    }
     NS_STAMP(7);
   };
   const int kind = ns_epi_kind(p);

@@ -21,6 +21,8 @@ rounding at every Linear/Conv output, exact-erf GELU evaluated on fp16 values.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 
@@ -184,6 +186,7 @@ class MegWhisperEngine:
         self._build_trainables(sd, lora_sd)
         self._bufs = {}
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
+        self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
@@ -456,6 +459,10 @@ class MegWhisperEngine:
             b["uo"] = [h16(M, r) for _ in range(nl)]
             b["u1"] = [h16(M, r) for _ in range(nl)]
             b["u2"] = [h16(M, r) for _ in range(nl)]
+            # fc2's adapter bottleneck as a side product of fc1's GELU epilogue (ns_gemm_desc.side_*): one (M x 32) fp32 slab per
+            # 256-column tile of the GELU output, summed by ns_gemm_side_reduce
+            if r == 32 and ops.gemm_side_supported(M, f, d) and not self.no_side_u2:
+                b["u2_slabs"] = torch.empty((f // 256) * M * 32, device=dev, dtype=F32)
         b["enc16"] = h16(M, d)
         b["enc_st"] = (f32(M), f32(M))
         nd = dims.dec_layers
@@ -514,8 +521,8 @@ class MegWhisperEngine:
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, x16, M, lin: _Lin, *, C16=None, ldc=None, G16=None, R32=None, H32=None, gelu=False,
-             A2=None, lda2=0, K2=0, B2=None, ngroup=0):
-        ops.gemm(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias,
+             A2=None, lda2=0, K2=0, B2=None, ngroup=0, **side):
+        ops.gemm(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, **side,
                  A2=A2, am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
                  a2_ngroup=ngroup,
                  C16=C16, c16m=rowmap(ldc or lin.N) if C16 is not None else None,
@@ -661,10 +668,16 @@ class MegWhisperEngine:
             if r:
                 ops.gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
+                side = train and "u2_slabs" in b and not self.no_side_u2
+                sk = dict(side_B=lo["fc2_A"], side_ldb=f, side_n=r, side_out=b["u2_slabs"], side_drop_p=dp,
+                          side_drop_seed=seed + 3) if side else {}
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True, A2=b["u1"][j], lda2=r,
-                          K2=r, B2=lo["fc1_sB"])
-                ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
-                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 3)
+                          K2=r, B2=lo["fc1_sB"], **sk)
+                if side:   # u2 = drop(gf) A^T / keep from the slabs the GELU epilogue left (no second pass over gf)
+                    ops.gemm_side_reduce(b["u2_slabs"], f // 256, M, self._drop_inv(), b["u2"][j], r)
+                else:
+                    ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
+                             flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 3)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
             else:
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True)

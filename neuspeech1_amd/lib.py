@@ -40,6 +40,9 @@ class GemmDesc(C.Structure):
         ("splits", C.c_int32),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
         ("alpha", C.c_float),
+        ("side_B", C.c_void_p), ("side_ldb", C.c_int32), ("side_n", C.c_int32),
+        ("side_out", C.c_void_p),
+        ("side_drop_p", C.c_float), ("side_drop_seed", C.c_uint32),
     ]
 
 
@@ -172,6 +175,8 @@ SIGNATURES = {
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_adalora_fold_jobs": (C.c_int, [_vp, _i, _vp]),
+    "ns_gemm_side_supported": (C.c_int, [_i, _i, _i]),
+    "ns_gemm_side_reduce": (C.c_int, [_vp, _i, _i, _f, _vp, _i, _vp]),
     "ns_orth_reg": (C.c_int, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "ns_orth_reg_workspace_bytes": (_sz, [_i]),
     "ns_lora_bwd_supported": (C.c_int, [_i, _i, _i]),

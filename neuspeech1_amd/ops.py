@@ -48,8 +48,11 @@ GEMM_PROFILE = None   # set to a list by bench.py to time every GEMM launch with
 
 def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
          bias=None, C16=None, c16m=None, G16=None, g16m=None, P16=None, p16m=None, R32=None, H32=None, h32m=None,
-         pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0):
+         pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0,
+         side_B=None, side_ldb=0, side_n=0, side_out=None, side_drop_p=0.0, side_drop_seed=0):
     d = GemmDesc()
+    d.side_B, d.side_ldb, d.side_n, d.side_out = ptr(side_B), side_ldb, side_n, ptr(side_out)
+    d.side_drop_p, d.side_drop_seed = side_drop_p, side_drop_seed
     d.A, d.am, d.K = ptr(A), am, K
     d.B = ptr(B)
     d.bm = bm if bm is not None else rowmap(ldb)
@@ -80,6 +83,14 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
     e1.record(torch.cuda.current_stream())
     GEMM_PROFILE.append((kind, 2.0 * M * N * (K + K2), e0, e1))
+
+
+def gemm_side_supported(M: int, N: int, K: int) -> bool:
+    return bool(L.load().ns_gemm_side_supported(M, N, K))
+
+
+def gemm_side_reduce(slabs, tiles, M, alpha, u16, ldu):
+    L.check(L.load().ns_gemm_side_reduce(ptr(slabs), tiles, M, alpha, ptr(u16), ldu, _stream()), "ns_gemm_side_reduce")
 
 
 def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5):

@@ -444,9 +444,11 @@ def test_base_shape_step_is_the_same_through_the_big_gemm_kernels(dev):
             eng = MegWhisperEngine(dims, sd, lora=LoraSpec(r=32, alpha=64.0, dropout=0.05), lora_sd=lora_sd,
                                    train_cfg=TrainCfg(lr=1e-3), device=dev)
             eng.drop_seed = 777
+            eng.no_side_u2 = mode == 0       # mode 1 also takes fc2's adapter bottleneck from fc1's GELU epilogue (side product)
             eng.zero_grad()
             loss, _ = eng.forward(xd, ld, train=True, compute_grad=True)
             eng.backward()
+            assert ("u2_slabs" in eng._b) == (mode == 1)
             res[mode] = (loss.item(), eng.G.clone(), eng._b["enc16"].float().clone())
             del eng
     finally:

@@ -257,6 +257,39 @@ def test_gemm_tn_conv_wgrad_256_tiles(ops, dev, Bn, T, Cin, Cout, stride):
         close(c3, a3.float().T @ b3.float(), 2e-1, 2e-3, "75 tiles of 256 x 256")
 
 
+@pytest.mark.parametrize("M,p", [(12000, 0.05), (12031, 0.0)])
+def test_gelu_epilogue_side_product(ops, dev, M, p):
+    """ns_gemm_desc.side_*: the large-M GELU GEMM (fc1) also leaves, per 256-column tile, the product of its masked fp16 GELU
+    output with a (32 x N) matrix (the next Linear's LoRA down-projection); ns_gemm_side_reduce sums the slabs.  Against torch
+    on the kernel's own GELU output, and against the stand-alone down-projection kernel; the main outputs must be unchanged."""
+    N, K, r, seed = 2048, 512, 32, 99
+    assert ops.gemm_side_supported(M, N, K) and not ops.gemm_side_supported(1000, N, K) and not ops.gemm_side_supported(M, N + 64, K)
+    x = rnd((M, K), dev, 1.0, seed=1)
+    W = rnd((N, K), dev, 0.05, seed=2)
+    bias = rnd((N,), dev, 0.2, torch.float32, seed=3)
+    A2 = rnd((r, N), dev, 0.05, seed=4)
+    pre, gf = torch.empty(M, N, device=dev, dtype=torch.float16), torch.empty(M, N, device=dev, dtype=torch.float16)
+    slabs = torch.full(((N // 256) * M * 32,), float("nan"), device=dev)
+    flags = ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD
+    ops.gemm(A=x, am=ops.rowmap(K), K=K, B=W, ldb=K, M=M, N=N, bias=bias, C16=pre, c16m=ops.rowmap(N), G16=gf, g16m=ops.rowmap(N),
+             flags=flags, side_B=A2, side_ldb=N, side_n=r, side_out=slabs, side_drop_p=p, side_drop_seed=seed)
+    keep, inv = _keep_mask(seed, M, N, p, dev) if p > 0 else (torch.ones(M, N, device=dev), 1.0)
+    u = torch.full((M, r + 8), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm_side_reduce(slabs, N // 256, M, inv, u, r + 8)
+    assert not torch.isnan(slabs).any() and torch.isnan(u[:, r:].float()).all()
+    ref = ((gf.float() * keep) @ A2.float().T) * inv
+    close(u[:, :r], ref, 2e-2, 5e-3, "side product vs torch on the kernel's GELU output")
+    # the stand-alone kernel it replaces
+    u2 = torch.empty(M, r, device=dev, dtype=torch.float16)
+    ops.gemm(A=gf, am=ops.rowmap(N), K=N, B=A2, ldb=N, M=M, N=r, C16=u2, c16m=ops.rowmap(r), flags=ops.NS_GEMM_DROP_A if p > 0 else 0,
+             alpha=inv, drop_p=p, drop_seed=seed)
+    close(u[:, :r], u2, 1e-2, 5e-3, "side product vs the down-projection kernel")
+    # main outputs unchanged by the side product
+    pre0, gf0 = torch.empty_like(pre), torch.empty_like(gf)
+    ops.gemm(A=x, am=ops.rowmap(K), K=K, B=W, ldb=K, M=M, N=N, bias=bias, C16=pre0, c16m=ops.rowmap(N), G16=gf0, g16m=ops.rowmap(N), flags=flags)
+    assert torch.equal(pre, pre0) and torch.equal(gf, gf0)
+
+
 # --------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,d", [(37, 256), (1000, 512), (130, 1280)])
 def test_layernorm(ops, dev, rows, d):
