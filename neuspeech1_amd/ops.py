@@ -82,7 +82,7 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
     e1.record(torch.cuda.current_stream())
-    GEMM_PROFILE.append((kind, 2.0 * M * N * (K + K2), e0, e1))
+    GEMM_PROFILE.append((kind, 2.0 * M * N * (K + K2 + (side_n if side_B is not None else 0)), e0, e1))   # side product: 2 M N side_n more
 
 
 def gemm_side_supported(M: int, N: int, K: int) -> bool:
