@@ -154,7 +154,7 @@ def main(argv=None):
         sequence_bias = GetSequenceBias(tokenizer_name=args.model_path, jsonl_path=args.test_data.replace("test.jsonl", "train.jsonl"),
                                         bias=-1.0, extract_type=args.sequence_bias_type, tokenizer=tok).get_bias_for_my_sentences()
         print(f"sequence bias: {len(sequence_bias)} token sequences")
-    preds, refs = [], []
+    preds, refs, tf_ids = [], [], []
     n_new, n_match, n_lab, t0 = 0, 0, 0, time.time()
     t_gen = 0.0
     txt_path = os.path.join(out_dir, base + ".txt") if world == 1 else os.devnull   # ranks > 1: rank 0 writes it after the gather
@@ -183,6 +183,7 @@ def main(argv=None):
                 n_match += int(((gen[:, :-1] == labels[:, 1:]) & ~ign[:, 1:]).sum())
                 n_lab += int((~ign[:, 1:]).sum())
                 gen = gen.masked_fill(ign, -100).numpy()
+                tf_ids.append(gen)
             if hasattr(x, "release"):
                 x.release()
             lab = np.where(labels.numpy() != -100, labels.numpy(), processor.tokenizer.pad_token_id)
@@ -226,6 +227,8 @@ def main(argv=None):
     print(f"results: {results}")
     with open(os.path.join(out_dir, base + ".json"), "w") as f:
         json.dump(results, f)
+    # callers in-process (tests) also get the model and, for --teacher_forcing, the argmax ids per batch (-100 on padding)
+    return dict(results, model=model, teacher_forced_ids=tf_ids)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,7 @@ def build_parser():
     add_arg("split_sentences", type=bool, default=False, help="sentence splitting")
     add_arg("ft_full", type=bool, default=False, help="adapt the whole model")
     # additions of this build (not in the reference)
+    add_arg("lora_dropout", type=float, default=None, help="adapter dropout (default: the reference's 0.05 LoRA / 0.1 AdaLoRA)")
     add_arg("max_steps", type=int, default=-1, help="stop after N optimizer steps (smoke runs)")
     add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack) "
                                                         "instead of in the data-loader workers")
@@ -287,10 +288,11 @@ def main(argv=None):
         print("modules_to_save", modules_to_save)
         if args.use_adalora:
             config = AdaLoraConfig(init_r=12, target_r=4, beta1=0.85, beta2=0.85, tinit=200, tfinal=1000, deltaT=10,
-                                   lora_alpha=32, lora_dropout=0.1, orth_reg_weight=0.5, target_modules=target_modules,
+                                   lora_alpha=32, lora_dropout=0.1 if args.lora_dropout is None else args.lora_dropout, orth_reg_weight=0.5, target_modules=target_modules,
                                    modules_to_save=modules_to_save)
         else:
-            config = LoraConfig(r=32, lora_alpha=64, target_modules=target_modules, lora_dropout=0.05, bias="none",
+            config = LoraConfig(r=32, lora_alpha=64, target_modules=target_modules,
+                                lora_dropout=0.05 if args.lora_dropout is None else args.lora_dropout, bias="none",
                                 modules_to_save=modules_to_save)
         model = get_peft_model(model, config)
     trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
@@ -359,6 +361,15 @@ def main(argv=None):
             mi, micro = 0, []
             step += 1
             loss_sum, loss_cnt = loss_sum + loss.detach().reshape(()).float(), loss_cnt + 1   # stays on the device
+            if step % args.logging_steps == 0 and ddp:
+                # HF Trainer logs the loss averaged over the ranks (`_nested_gather(tr_loss).mean()`), not rank 0's shard
+                if torch.distributed.get_backend() == "gloo":
+                    t_ = loss_sum.cpu()
+                    torch.distributed.all_reduce(t_)
+                    loss_sum = t_.to(whisper.device) / world
+                else:
+                    torch.distributed.all_reduce(loss_sum)
+                    loss_sum = loss_sum / world
             if step % args.logging_steps == 0 and rank == 0:
                 # HF Trainer logs the MEAN training loss of the steps since the previous log line
                 mean_loss = (loss_sum / loss_cnt).item()        # waits for the interval's kernels: dt below is a GPU rate
@@ -369,6 +380,7 @@ def main(argv=None):
                 with open(log_path, "a") as f:
                     f.write(json.dumps(rec) + "\n")
                 t_log, n_log = time.time(), 0
+            if step % args.logging_steps == 0:
                 loss_sum, loss_cnt = torch.zeros((), device=whisper.device), 0
             # SavePeftModelCallback.on_step_end (utils/callback.py:12-22) decides BEFORE this step's evaluation: save at a
             # multiple of save_steps iff the most recent eval loss on record is the minimum of all recorded ones

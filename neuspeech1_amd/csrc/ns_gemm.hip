@@ -466,6 +466,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
   const size_t lds = 2 * TILE_BYTES + 2 * (size_t)bn * BK * 2;   // BN=128: 64 KiB (= the fp32 epilogue tile)
   hipStream_t st = (hipStream_t)stream;
+  NS_CHECK_ARG(!d->side_B || !(skinny || ns_gemm_skinny_ok(d) || ns_gemm_smallm_ok(d) || (d->flags & NS_GEMM_DROP_A)),
+               "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
   if (tn && g_use_ring != 0 && g_use_ring != 8 && ns_gemm_tn256_ok(d)) {
     ns_gemm_tn256_launch(d, st);   // conv-stem weight gradients: 256 x 256 LDS-DMA tiles (mode 8 = off, for A/B runs)
   } else if (tn && (g_use_ring || (d->flags & NS_GEMM_COLSUM_A)) && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
@@ -492,9 +494,15 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
     if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1)) ns_gemm_p8_launch(d, st);
-    else if (big) ns_gemm_ring256_launch(d, st);
-    else ns_gemm_ring_launch(d, st);
+    else {
+      // only ns_gemm_p8_kernel forms the side product: any other kernel would leave side_out unwritten and the caller's
+      // ns_gemm_side_reduce would sum garbage -- refuse instead (e.g. a shape past ns_gemm_p8_fits' 2 GiB limit)
+      NS_CHECK_ARG(!d->side_B, "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
+      if (big) ns_gemm_ring256_launch(d, st);
+      else ns_gemm_ring_launch(d, st);
+    }
   } else {
+    NS_CHECK_ARG(!d->side_B, "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
     if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);
   }
   NS_CHECK_LAUNCH("ns_gemm");

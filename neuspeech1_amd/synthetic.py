@@ -92,8 +92,10 @@ class SyntheticProcessor:
 
 
 def write_synthetic_dataset(root: str, n: int, ch_file: int = 224, name: str = "gwilliams", seed: int = 0,
-                            min_len: int = 700, max_len: int = 7000):
-    """n samples of shape (ch_file, len) float64 in [-1, 1] + a JSONL list in the reference's schema."""
+                            min_len: int = 700, max_len: int = 7000, fixed_chars: int | None = None):
+    """n samples of shape (ch_file, len) float64 in [-1, 1] + a JSONL list in the reference's schema.
+    fixed_chars: every sentence cut / padded to exactly that many characters (equal label lengths: a per-rank token mean
+    then equals the global one, which the data-parallel tests rely on)."""
     os.makedirs(os.path.join(root, name), exist_ok=True)
     rng = np.random.default_rng(seed)
     rows = []
@@ -105,6 +107,8 @@ def write_synthetic_dataset(root: str, n: int, ch_file: int = 224, name: str = "
         np.save(path, x)
         chosen = [str(w) for w in rng.choice(words, size=int(rng.integers(3, 9)))]
         sent = " ".join(chosen)
+        if fixed_chars is not None:
+            sent = (sent + " " + " ".join(words))[:fixed_chars].rstrip().ljust(fixed_chars, "x")
         # per-sentence / per-word timing records for --timestamps=True (finetune.py's default): words spread over the signal
         step = (L / 200.0) / (len(chosen) + 1)
         wrec = [{"start": round(step * (k + 0.5), 2), "end": round(step * (k + 1.4), 2), "word": w} for k, w in enumerate(chosen)]

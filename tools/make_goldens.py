@@ -16,7 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from neuspeech1_amd.weights import LV2W, TINY, WHISPER_BASE, WhisperDims, make_lora_state, make_state_dict, synth_batch  # noqa: E402
+from neuspeech1_amd.weights import LV2W, TINY, WHISPER_BASE, WHISPER_LARGE_V2, WhisperDims, make_lora_state, make_state_dict, synth_batch  # noqa: E402
 
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -130,6 +130,27 @@ def adalora_golden(dims, tag, B, r=12, alpha=32.0):
     np.savez_compressed(os.path.join(OUT, f"adalora_merged_{tag}.npz"), loss=np.float32(out.loss.item()),
                         loss_base=np.float32(base.loss.item()), logits=lg[:, :, ::3], r=r, alpha=alpha, B=B, b_std=0.3)
     print(f"adalora_merged_{tag}: loss {out.loss.item():.6f} (frozen model {base.loss.item():.6f})")
+
+
+def lora_oracle_golden(dims, tag, B, r=32, alpha=64.0, seed_d=31):
+    """Adapter gradients at a size where running the oracle inside a GPU test would take minutes (whisper-large-v2 at
+    full depth): the ORACLE's loss and per-tensor gradient norms + leading blocks with LoRA r = 32 on every encoder
+    projection (the oracle's adapter arithmetic is pinned on the reference object through merged weights by
+    lora_merged_*.npz; the frozen path of the same config is pinned directly by train_<tag>.npz)."""
+    from oracle import whisper_meg_oracle as O
+    sd_np = make_state_dict(dims, 42)
+    lora_np = make_lora_state(dims, r)
+    x, labels = synth_batch(dims, B, seed_d)
+    loss, logits, enc, grads = O.loss_and_grads(sd_np, lora_np, x, labels, dims, alpha / r)
+    g = {"loss": np.float32(loss.item()), "B": B, "r": r, "alpha": alpha, "seed_d": seed_d, "labels": labels}
+    names = sorted(grads)
+    g["names"] = np.array(names)
+    g["gradnorm"] = np.array([float(grads[k].double().norm()) for k in names], dtype=np.float64)
+    g["gradblock"] = np.stack([np.pad(grads[k].reshape(grads[k].shape[0], -1)[:8, :8].numpy().astype(np.float32),
+                                      ((0, 8 - min(8, grads[k].shape[0])), (0, 8 - min(8, grads[k].reshape(grads[k].shape[0], -1).shape[1]))))
+                               for k in names])
+    np.savez_compressed(os.path.join(OUT, f"lora_oracle_{tag}.npz"), **g)
+    print(f"lora_oracle_{tag}: loss {g['loss']:.6f}, {len(names)} gradient tensors")
 
 
 class _ForceTokens:
@@ -325,6 +346,11 @@ if __name__ == "__main__":
         # BASELINE configs[4] WIDTH (whisper-large-v2: d=1280, 20 heads, ffn 5120, 273 channels) at 2+2 layers
         train_golden(LV2W, "lv2w", B=1, full=False)
         decode_golden(LV2W, "lv2w", B=2, new_tokens=12, eos_variants=())
+    if "lv2" in what:
+        # BASELINE configs[4] at FULL depth (whisper-large-v2: 32 + 32 layers, d 1280, 273 channels), B = 1: the frozen path on
+        # the reference object, the adapter gradients on the oracle
+        train_golden(WHISPER_LARGE_V2, "lv2", B=1, full=False)
+        lora_oracle_golden(WHISPER_LARGE_V2, "lv2", B=1)
     if "forced" in what:
         decode_forced_golden(TINY, "tiny", B=3, new_tokens=20)
     if "hf_ckpt" in what:

@@ -411,7 +411,14 @@ class WhisperForConditionalGeneration(nn.Module):
             return fallback
 
         def one(v):
-            return v[0] if isinstance(v, (list, tuple)) else v
+            # HF treats EVERY id of a list-valued eos_token_id as end-of-sequence; the decode kernels take one id.  The
+            # openai/whisper-* generation configs carry a single id (50257); a checkpoint listing several would silently
+            # decode past the others, so refuse it rather than collapse it to its first element
+            if isinstance(v, (list, tuple)):
+                if len(set(v)) > 1:
+                    raise NotImplementedError(f"generate: several end-of-sequence / pad ids {list(v)} (the HIP decode loop stops on one id)")
+                return v[0]
+            return v
 
         if decoder_input_ids is None:
             decoder_input_ids = torch.full((x.shape[0], 1), default("decoder_start_token_id"), dtype=torch.int64)
