@@ -27,6 +27,7 @@ GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
 # fwd+bwd" is measured on
 ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
+PMC_FILE = "profiles/r2_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 
 
 def cpu_baseline(dims, r, alpha):
@@ -67,7 +68,7 @@ def _pmc_traffic(kernel):
     by tools/profile.sh pmc + tools/pmc_summary.py.  The file records the sha256 of the kernel's source; a file measured
     on a different kernel revision is refused (traffic: null) rather than reported."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         if not kernel or d.get("kernel") != kernel or d.get("kernel_source_sha256_16") != _kernel_source_hash():
             return None
         return round(d["hbm_bytes_per_launch"])
@@ -84,27 +85,11 @@ def cpu_reference_object(dims, B=4):
     evaluation.py:369-386)."""
     import torch
     import transformers
-    from transformers import WhisperConfig, WhisperForConditionalGeneration
-    from neuspeech1_amd.weights import make_state_dict, synth_batch
-    from utils.model_utils import projection_module
+    from neuspeech1_amd.weights import synth_batch
+    from tools.hf_reference_object import build_reference_object, generate, generate_kwargs
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    cfg = WhisperConfig(vocab_size=dims.vocab, num_mel_bins=80, d_model=dims.d, encoder_layers=dims.enc_layers,
-                        decoder_layers=dims.dec_layers, encoder_attention_heads=dims.heads,
-                        decoder_attention_heads=dims.heads, encoder_ffn_dim=dims.ffn, decoder_ffn_dim=dims.ffn,
-                        max_source_positions=dims.src_pos, max_target_positions=dims.tgt_pos, pad_token_id=dims.pad_id,
-                        bos_token_id=dims.bos_id, eos_token_id=dims.eos_id, decoder_start_token_id=dims.start_id,
-                        attn_implementation="eager", suppress_tokens=[], begin_suppress_tokens=[])
-    model = WhisperForConditionalGeneration(cfg)
-    model.model.encoder.set_input_embeddings(projection_module(config_name="base", meg_ch=dims.ch, d_model=dims.d))
-    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(dims, 42).items()}
-    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
-    model.load_state_dict(sd, strict=False)
-    for p_ in model.parameters():
-        p_.requires_grad_(False)
-    for n_, p_ in model.named_parameters():
-        if n_.startswith("model.encoder.conv"):
-            p_.requires_grad_(True)
+    model = build_reference_object(dims, "cpu")
     x, labels = synth_batch(dims, B, 1234)
     xt, lt = torch.from_numpy(x), torch.from_numpy(labels)
 
@@ -118,17 +103,73 @@ def cpu_reference_object(dims, B=4):
         step()
     train = B * 3 / (time.perf_counter() - t0)
     model.eval()
-    out = {"kind": "reference-object", "cores": cores, "train_samples_per_s": round(train, 4), "unit_decode": "tokens/s",
+    out = {"value": round(train, 4), "unit": "samples/s", "cores": cores, "kind": "reference",
+           "kind_detail": "reference object: stock transformers Whisper + the conv stack, i.e. what /root/reference/evaluation.py:72-86 "
+                          "builds (the reference's own files cannot travel to the GPU box; peft is not in the image)",
+           "unit_decode": "tokens/s",
            "sample": f"stock transformers {transformers.__version__} Whisper (eager, fp32) + conv stack, whisper-base {dims.ch}-ch, "
                      f"B={B}: 1+3 fwd+bwd passes; GenerationMixin.generate 40 new tokens"}
-    common = dict(do_sample=False, max_new_tokens=40, decoder_input_ids=lt[:, :4].clone(), suppress_tokens=[dims.eos_id],
-                  begin_suppress_tokens=None, pad_token_id=dims.pad_id, eos_token_id=dims.eos_id)
-    gen = transformers.GenerationMixin.generate
     with torch.no_grad():
         for name, kw in (("greedy", dict(num_beams=1)), ("beam5_rep5_ngram2", dict(num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2))):
             t0 = time.perf_counter()
-            o = gen(model, xt, **kw, **common)
+            o = generate(model, xt, **kw, **generate_kwargs(dims, lt[:, :4].clone(), 40, suppress_eos=True))
             out[name] = round(B * (o.shape[1] - 4) / (time.perf_counter() - t0), 2)
+    return out
+
+
+def gpu_reference_object(dev, B_train=64, B_dec=128, new=64):
+    """Context, never `value`: the SAME reference object on this GPU through stock PyTorch-ROCm under
+    torch.autocast('cuda', fp16) -- the reference's own numerics and call shapes (finetune.py:242, evaluation.py:350,
+    369-386) -- i.e. what a user of the reference gets on an MI355X without this library.  Train: whisper-base 208-ch,
+    B=64, loss scaled by 65536, 1 warm-up + 3 timed forward+backward passes (trainables = the conv stem; no adapters:
+    peft is not in the image).  Decode: whisper-base 273-ch, B=128, 64 new tokens with EOS suppressed, greedy and
+    beam-5 + repetition penalty 5 + no-repeat-2."""
+    import torch
+    import transformers
+    from neuspeech1_amd.weights import WhisperDims, synth_batch
+    from tools.hf_reference_object import build_reference_object, generate, generate_kwargs
+    out = {"kind": "reference object through stock PyTorch-ROCm, fp16 autocast, eager attention", "torch": torch.__version__,
+           "transformers": transformers.__version__}
+    dims = WhisperDims()
+    model = build_reference_object(dims, dev)
+    model.train()
+    x, labels = synth_batch(dims, B_train, 1234)
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = model(input_features=xt, labels=lt).loss
+        (loss * 65536.0).backward()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    out["train_samples_per_s"] = round(B_train * 3 / (time.perf_counter() - t0), 2)
+    out["train_sample"] = f"whisper-base 208-ch, B={B_train}, 1+3 fwd+bwd passes"
+    del model, xt, lt
+    torch.cuda.empty_cache()
+    dims = WhisperDims(ch=273)
+    model = build_reference_object(dims, dev, train_convs=False)
+    x, labels = synth_batch(dims, B_dec, 1234)
+    xt, pr = torch.from_numpy(x).to(dev), torch.from_numpy(labels[:, :4].copy()).to(dev)
+    out["unit_decode"] = "tokens/s"
+    out["decode_sample"] = f"whisper-base 273-ch, B={B_dec}, prompt 4, {new} new tokens, EOS suppressed, encoder pass included"
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for name, kw in (("greedy", dict(num_beams=1)), ("beam5_rep5_ngram2", dict(num_beams=5, repetition_penalty=5.0, no_repeat_ngram_size=2))):
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o = generate(model, xt, **kw, **generate_kwargs(dims, pr.clone(), new, suppress_eos=True))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out[name] = round(B_dec * (o.shape[1] - 4) / best, 1)
+    del model
+    torch.cuda.empty_cache()
     return out
 
 
@@ -246,6 +287,7 @@ def main():
     xd = torch.from_numpy(x).to(dev)
     ld = torch.from_numpy(labels).to(dev)
     red = GradReducer(eng.G) if world > 1 else None
+    eng_graph = eng.use_graph
 
     def step():
         if red is None:
@@ -260,10 +302,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0     # host time to ENQUEUE the timed steps (hipGraph replays; nothing waits for the GPU)
     if world > 1:
+        torch.cuda.synchronize()
+        t_local = time.perf_counter()       # this rank's own finish, before the barrier levels the ranks
         dist.barrier()
     torch.cuda.synchronize()
+    if world == 1:
+        t_local = time.perf_counter()
     dt = time.perf_counter() - t0
+    dt_local = t_local - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,7 +337,8 @@ def main():
         ach = fl / sec / 1e12
         roof = {"bound": "mfma", "kernel": "ns_gemm_p8_kernel" if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": _pmc_traffic("ns_gemm_p8_kernel" if dom == "nt256" else None), "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                "traffic": _pmc_traffic("ns_gemm_p8_kernel" if dom == "nt256" else None), "traffic_source": PMC_FILE,
+                "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                 "gflop_per_launch": round(fl / n / 1e9, 2),
                 "step_share": {k: {"ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 1),
                                    "launches": v[2]} for k, v in tot.items()}}
@@ -311,22 +360,36 @@ def main():
     if red is not None:
         torch.cuda.synchronize()
         ms_, by_ = red.exposed_ms(last=args.steps)
-        dp = {"allreduce_bytes_per_step": by_, "exposed_allreduce_ms_per_step": round(ms_, 4), "chunks": 3,
+        # every rank's own wall time over the timed steps: the skew says whether one rank (host, clocks, a slow GPU) holds
+        # the others at the collective
+        mine = torch.tensor([dt_local / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(t.item()), 3) for t in allr]
+        dp = {"allreduce_bytes_per_step": by_, "exposed_allreduce_ms_per_step": round(ms_, 4),
+              "allreduce_ms_per_step": round(red.total_ms(last=args.steps), 4), "chunks": 3,
+              "rank_ms_per_step": per_rank, "rank_skew_ms": round(max(per_rank) - min(per_rank), 3),
               "backend": os.environ.get("NS_DIST_BACKEND", "nccl")}
 
-    cpu = cpu_ref = None
+    cpu = cpu_port = gpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(dims, args.lora_r, 2.0 * args.lora_r)
+        # `cpu_baseline` = SURVEY 8(d)'s leg (the reference object, B = 4, on the host cores); the oracle port beside it
+        cpu_port = cpu_baseline(dims, args.lora_r, 2.0 * args.lora_r)
         try:
-            cpu_ref = cpu_reference_object(dims)
+            cpu = cpu_reference_object(dims)
         except Exception as e:      # a reported baseline, not the product: never fail the bench line over it
-            cpu_ref = {"kind": "reference-object", "error": repr(e)[:200]}
+            cpu = dict(cpu_port, note="reference-object leg failed: " + repr(e)[:160])
 
     ev = None
     if rank == 0 and world == 1 and not args.no_eval:
         del eng
         torch.cuda.empty_cache()
         ev = eval_tokens_per_s(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_eval:
+        try:
+            gpu_ref = gpu_reference_object(dev)
+        except Exception as e:
+            gpu_ref = {"error": repr(e)[:200]}
 
     if world > 1:
         dist.barrier()
@@ -344,9 +407,10 @@ def main():
                        "algorithmic_gflop_per_sample": gf,
                        "whole_step_mfma_frac": round(value / world * gf * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
                        "encoder_fwd_bwd_mfma_frac": enc["mfma_frac"] if enc else None,
-                       "final_loss": round(loss_v, 4)},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_reference_object": cpu_ref, "encoder_fwd_bwd": enc,
-            "dp": dp, "eval": ev,
+                       "final_loss": round(loss_v, 4),
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "train_step_graph": bool(eng_graph)},
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "torch_rocm_reference_object": gpu_ref,
+            "encoder_fwd_bwd": enc, "dp": dp, "eval": ev,
         }
         print(json.dumps(out), flush=True)
 

@@ -35,7 +35,7 @@ typedef enum {
   NS_ERR_HIP = -3
 } ns_status;
 
-int ns_version(void);                 /* ABI version, currently 1 */
+int ns_version(void);                 /* ABI version, currently 2 (bumped with every descriptor-layout / signature change) */
 const char* ns_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------
@@ -125,6 +125,11 @@ typedef struct {
   const void* side_B; int32_t side_ldb, side_n;
   float* side_out;
   float side_drop_p; uint32_t side_drop_seed;
+  /* Device-resident step counter for the dropout masks (ABI 2): when non-NULL every mask of this launch uses
+     seed + (*seed_dev) * 0x9E3779B1 in place of seed (drop_seed and side_drop_seed alike).  The training step then has
+     no launch argument that changes from step to step, which is what lets it be captured in a hipGraph: the counter is
+     advanced on the device (by the optimizer step), the graph is replayed unchanged. */
+  const uint32_t* seed_dev;
 } ns_gemm_desc;
 
 int ns_gemm(const ns_gemm_desc* d, void* stream);

@@ -97,6 +97,10 @@ __device__ __forceinline__ uint32_t ns_hash3(uint32_t seed, uint32_t a, uint32_t
   x ^= x >> 16;
   return x;
 }
+// effective dropout seed of a launch: ns_gemm_desc.seed_dev (a device-resident step counter, wave-uniform scalar load) folded in
+__device__ __forceinline__ uint32_t ns_eff_seed(uint32_t seed, const uint32_t* seed_dev) {
+  return seed_dev ? seed + *seed_dev * 0x9E3779B1u : seed;
+}
 __device__ __forceinline__ uint32_t ns_drop_thr8(float p) { return (uint32_t)(p * 256.0f + 0.5f); }
 __device__ __forceinline__ float ns_drop_inv(float p) { return 256.0f / (256.0f - (float)ns_drop_thr8(p)); }
 // The kernels apply the keep MASK only; the survivors' 1/(1 - thr8/256) rides in the caller's `alpha` (forward

@@ -41,6 +41,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 
 template <bool TN, int BN, bool DROP>
 __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc p) {
+  const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BTILE_BYTES = BN * BK * 2;
   constexpr int WT_M = BN == 128 ? 2 : 1, WT_N = BN == 128 ? 2 : 1, WAVE_M = 32 * WT_M, WAVE_N = 32 * WT_N;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
         const uint32_t grow = (uint32_t)(m0 + st_row + 32 * it);
         uint32_t w[4] = {st.a[it].x, st.a[it].y, st.a[it].z, st.a[it].w};
         uint32_t m[4];
-        ns_keep_masks(ns_drop_word(p.drop_seed, grow, (uint32_t)ko >> 2), drop_thr, m[0], m[1]);
-        ns_keep_masks(ns_drop_word(p.drop_seed, grow, ((uint32_t)ko >> 2) + 1), drop_thr, m[2], m[3]);
+        ns_keep_masks(ns_drop_word(dseed, grow, (uint32_t)ko >> 2), drop_thr, m[0], m[1]);
+        ns_keep_masks(ns_drop_word(dseed, grow, ((uint32_t)ko >> 2) + 1), drop_thr, m[2], m[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] &= m[e];
         st.a[it] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
           if (DROP && mask_b) {
             const uint32_t grow = (uint32_t)(kb + rl);
             half2v hv = __builtin_bit_cast(half2v, v);
-            const uint32_t dwd = ns_drop_word(p.drop_seed, grow, (uint32_t)col >> 2);
+            const uint32_t dwd = ns_drop_word(dseed, grow, (uint32_t)col >> 2);
             hv[0] = ns_keep(dwd, (uint32_t)col, drop_thr) ? hv[0] : (half_t)0.f;
             hv[1] = ns_keep(dwd, (uint32_t)col + 1, drop_thr) ? hv[1] : (half_t)0.f;
             v = __builtin_bit_cast(uint32_t, hv);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
             for (int r = 0; r < 16; ++r) {
               const uint32_t row = (uint32_t)(m0 + wm * WAVE_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
               const uint32_t col = (uint32_t)(n0 + wn * WAVE_N + j * 32 + lr);
-              acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
+              acc[i][j][r] = ns_keep_el(dseed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
             }
       }
       if (more) { if constexpr (TN) store_tn(cur ^ 1, NS_ST8); else store_nt(cur ^ 1, NS_ST8); }

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     if (DROP) {
       // LoRA-dropout mask on the (A2, B2) product, before the main product accumulates on top
       const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
+      const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
             for (int j = 0; j < 2; ++j) {
               const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
               const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
-              const uint32_t w = ns_drop_word(p.drop_seed, row, col >> 2);
+              const uint32_t w = ns_drop_word(dseed, row, col >> 2);
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] : 0.f;
             }
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
     const bool do_gelu = p.flags & NS_GEMM_GELU;
     const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
     const uint32_t side_thr = (KIND == NS_EPI_PLAIN && p.side_B && p.side_drop_p > 0.f) ? ns_drop_thr8(p.side_drop_p) : 0u;
+    const uint32_t side_dseed = side_thr ? ns_eff_seed(p.side_drop_seed, p.seed_dev) : 0u;
     f32x4 res[KIND == NS_EPI_RES ? 16 : 1][2];
     half8 pre[KIND == NS_EPI_DGELU ? 16 : 1];
     auto prefetch = [&](int i0) __attribute__((always_inline)) {
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
           uint4 w = __builtin_bit_cast(uint4, gv);
           if (side_thr) {
             uint32_t mk[4];
-            ns_keep_masks(ns_drop_word(p.side_drop_seed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
-            ns_keep_masks(ns_drop_word(p.side_drop_seed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
+            ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
+            ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
             w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
           }
           *(uint4*)(hs + rl * LDH + ecg * 16) = w;

@@ -32,6 +32,7 @@ __device__ __attribute__((aligned(16))) const uint32_t ns_zero_chunk[4] = {0, 0,
 
 template <bool DROP>
 __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring256_kernel(const ns_gemm_desc p) {
+  const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring256_kernel(const ns_gemm_d
           for (int r = 0; r < 16; ++r) {
             const uint32_t row = (uint32_t)(m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
             const uint32_t col = (uint32_t)(n0 + wn * 64 + j * 32 + lr);
-            acc[i][j][r] = ns_keep_el(p.drop_seed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
+            acc[i][j][r] = ns_keep_el(dseed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
           }
     }
   }

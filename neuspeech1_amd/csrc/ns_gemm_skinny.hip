@@ -26,6 +26,7 @@ typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NTILES, bool DROP, int SK_DEPTH>
 __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_desc p) {
+  const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_lds[];
   constexpr int N = 16 * NTILES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_
         if (DROP) {
           const uint32_t c4 = (uint32_t)(64 * s + 16 * lg) >> 2;
           uint32_t m[8];
-          ns_keep_masks(ns_drop_word(p.drop_seed, grow, c4), thr, m[0], m[1]);
-          ns_keep_masks(ns_drop_word(p.drop_seed, grow, c4 + 1), thr, m[2], m[3]);
-          ns_keep_masks(ns_drop_word(p.drop_seed, grow, c4 + 2), thr, m[4], m[5]);
-          ns_keep_masks(ns_drop_word(p.drop_seed, grow, c4 + 3), thr, m[6], m[7]);
+          ns_keep_masks(ns_drop_word(dseed, grow, c4), thr, m[0], m[1]);
+          ns_keep_masks(ns_drop_word(dseed, grow, c4 + 1), thr, m[2], m[3]);
+          ns_keep_masks(ns_drop_word(dseed, grow, c4 + 2), thr, m[4], m[5]);
+          ns_keep_masks(ns_drop_word(dseed, grow, c4 + 3), thr, m[6], m[7]);
           uint4 w0 = *(uint4*)&x0, w1 = *(uint4*)&x1;
           w0.x &= m[0]; w0.y &= m[1]; w0.z &= m[2]; w0.w &= m[3];
           w1.x &= m[4]; w1.y &= m[5]; w1.z &= m[6]; w1.w &= m[7];

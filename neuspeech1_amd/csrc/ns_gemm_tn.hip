@@ -30,6 +30,7 @@ __device__ __forceinline__ half8 tr_frag(const char* tile, int stride, int m0, i
 
 template <int BI, int BJ, bool DROP>
 __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p) {
+  const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SA = RowStride<BI>::bytes, SB = RowStride<BJ>::bytes;
   constexpr int A_BYTES = BKM * SA, B_BYTES = BKM * SB;
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
         const uint32_t grow = (uint32_t)(k_begin + step * BKM + rl);
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t m[4];
-        ns_keep_masks(ns_drop_word(p.drop_seed, grow, (uint32_t)colb >> 2), drop_thr, m[0], m[1]);
-        ns_keep_masks(ns_drop_word(p.drop_seed, grow, ((uint32_t)colb >> 2) + 1), drop_thr, m[2], m[3]);
+        ns_keep_masks(ns_drop_word(dseed, grow, (uint32_t)colb >> 2), drop_thr, m[0], m[1]);
+        ns_keep_masks(ns_drop_word(dseed, grow, ((uint32_t)colb >> 2) + 1), drop_thr, m[2], m[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] &= m[e];
         v = make_uint4(w[0], w[1], w[2], w[3]);

@@ -10,7 +10,7 @@ void ns_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-extern "C" int ns_version(void) { return 1; }
+extern "C" int ns_version(void) { return 2; }   // 2: ns_gemm_desc.seed_dev
 extern "C" const char* ns_last_error(void) { return g_err; }
 
 namespace {

@@ -28,6 +28,15 @@ class GradReducer:
         self.chunks = []
         self.bytes_per_step = 0
         self._waits = []          # (event before, event after) the optimizer stream's wait for the side stream, per step
+        # events are allocated ONCE and reused round-robin (a step records at most 3 chunk-ready events and, while the
+        # diagnosis is on, 2 + 2 x 3 timing events): nothing is created on the step path
+        self._ready_ev = [torch.cuda.Event() for _ in range(8)] if self.cuda else []
+        self._ready_i = 0
+        self.timing = True        # side-stream events around every chunk's collective (total vs exposed time); bench / tests
+        self._tpool, self._ti = [], 0
+        self._chunk_t = []        # per step: [(event before, event after) on the side stream per chunk]
+        self._cur_t = []
+        self.keep = 256           # steps of timing history kept (ring)
 
     def on_ready(self, lo: int, hi: int):
         """G[lo:hi] is final on the current stream: start its all-reduce on the side stream."""
@@ -37,13 +46,31 @@ class GradReducer:
         self.bytes_per_step += 4 * (hi - lo)
         view = self.G[lo:hi]
         if self.cuda:
-            ev = torch.cuda.Event()
+            ev = self._ready_ev[self._ready_i % len(self._ready_ev)]
+            self._ready_i += 1
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                self._reduce(view)
+                if self.timing:
+                    t0, t1 = self._tev(), self._tev()
+                    t0.record(self.side)
+                    self._reduce(view)
+                    t1.record(self.side)
+                    self._cur_t.append((t0, t1))
+                else:
+                    self._reduce(view)
         else:
             self._reduce(view)
+
+    def _tev(self):
+        """timing events from a ring sized for `keep` steps of history"""
+        n = self.keep * 8
+        if len(self._tpool) < n:
+            self._tpool.append(torch.cuda.Event(enable_timing=True))
+            return self._tpool[-1]
+        e = self._tpool[self._ti % n]
+        self._ti += 1
+        return e
 
     def _reduce(self, view):
         if self.native_avg:
@@ -56,12 +83,16 @@ class GradReducer:
         """Make the optimizer (current stream) wait for every chunk."""
         if self.cuda and (self.world > 1 or self.force):
             cur = torch.cuda.current_stream()
-            if len(self._waits) < 4096:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if self.timing:
+                e0, e1 = self._tev(), self._tev()
                 e0.record(cur)
                 cur.wait_stream(self.side)
                 e1.record(cur)
                 self._waits.append((e0, e1, self.bytes_per_step))
+                self._chunk_t.append(self._cur_t)
+                self._cur_t = []
+                if len(self._waits) > self.keep:
+                    del self._waits[0], self._chunk_t[0]
             else:
                 cur.wait_stream(self.side)
         self.chunks.clear()
@@ -75,3 +106,11 @@ class GradReducer:
         if not w:
             return 0.0, 0
         return sum(e0.elapsed_time(e1) for e0, e1, _ in w) / len(w), w[-1][2]
+
+    def total_ms(self, last: int | None = None):
+        """Per step: the collective time itself (sum over the chunks of the side stream's time inside all_reduce), the
+        quantity `exposed_ms` is a part of: exposed < total means backward hid some of it (call after a synchronize)."""
+        c = self._chunk_t[-last:] if last else self._chunk_t
+        if not c:
+            return 0.0
+        return sum(sum(t0.elapsed_time(t1) for t0, t1 in step) for step in c) / len(c)

@@ -30,7 +30,7 @@ import torch
 
 from . import ops
 from .feed import PackedSignal
-from .lib import AdamWCfg
+from .lib import GPU_CAPTURE_LOCK, AdamWCfg
 from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_COLSUM_A, NS_GEMM_DROP_A, NS_GEMM_GELU, NS_GEMM_GELU_SAVE_GRAD, NS_GEMM_MUL_P16, NS_GEMM_TN,
                   rowmap)
 
@@ -185,6 +185,9 @@ class MegWhisperEngine:
         self.dec_ln = (g(dd + "layer_norm.weight"), g(dd + "layer_norm.bias"))
         self._build_trainables(sd, lora_sd)
         self._bufs = {}
+        # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
+        self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
+        self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 24, 0
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
         self._init_opt_state()
@@ -402,6 +405,7 @@ class MegWhisperEngine:
                                ga(k + ".lora_E"), no, r, sc_))
                 self._fold_tables.append(ops.make_fold_jobs(fj, self.dev))
             self.reg_dev = torch.zeros(1, device=self.dev)
+            self.total_loss_dev = torch.zeros(1, device=self.dev)
             self._gbf = torch.zeros(max(d, f) * r, device=self.dev, dtype=F32)
             self._gbf3 = torch.zeros(max(3 * d, f) * r, device=self.dev, dtype=F32)
         self.refresh_operands()
@@ -421,20 +425,38 @@ class MegWhisperEngine:
         self.norm_ws = torch.empty(8192, device=dev, dtype=torch.uint8)
         self.loss_dev = torch.zeros(1, device=dev)
         self.nvalid_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        # LoRA-dropout seeds: `drop_seed` is the run's (per-rank) base and never changes on the host; what makes step t's
+        # masks differ from step t-1's is a DEVICE counter that optimizer_step advances and every masked launch reads
+        # (ns_gemm_desc.seed_dev) -- no launch argument varies from step to step, so a captured step replays unchanged
         self.drop_seed = 0x1234
+        self.seed_ctr = torch.zeros(1, device=dev, dtype=torch.int32)
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B: int, L: int, train: bool):
+        """Activation / gradient buffers of one (batch, label length).  Everything sized by the ENCODER rows (B * 1500:
+        ~17 GB at B = 64) is keyed by the batch size alone and shared by every label length; only the decoder-row buffers
+        (B * L rows, ~0.6 GB) exist per length -- label lengths vary from batch to batch in the reference's recipes."""
         key = (B, L, train)
+        if key in self._bufs:
+            return self._bufs[key]
+        b = dict(self._alloc_enc(B, train))
+        if L > 0:
+            b.update(self._alloc_dec(B, L, train))
+        b["L"] = L
+        self._bufs[key] = b
+        return b
+
+    def _alloc_enc(self, B: int, train: bool):
+        key = (B, "enc", train)
         if key in self._bufs:
             return self._bufs[key]
         dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
         T, S, Cp = dims.T, dims.src_pos, dims.ch_pad
-        M, ML = B * S, B * L
+        M = B * S
         dev = self.dev
         h16 = lambda *s: torch.zeros(*s, device=dev, dtype=F16)  # noqa: E731  (zeros: halo rows must be 0)
         f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
-        b = {"B": B, "L": L}
+        b = {"B": B}
         b["xin"] = h16(B, T + 2, Cp)
         if self.frontend == "base":
             b["pre0"] = h16(B * T, d)
@@ -465,29 +487,10 @@ class MegWhisperEngine:
                 b["u2_slabs"] = torch.empty((f // 256) * M * 32, device=dev, dtype=F32)
         b["enc16"] = h16(M, d)
         b["enc_st"] = (f32(M), f32(M))
-        nd = dims.dec_layers
-        ndl = nd if train else 1
-        if L > 0:
-            b["hd"] = [f32(ML, d) for _ in range((3 * nd + 1) if train else 2)]
-            for k in ("xs", "xc", "xm", "ao_s", "ao_c", "q_c"):
-                b[k] = [h16(ML, d) for _ in range(ndl)]
-            for k in ("st_s", "st_c", "st_m"):
-                b[k] = [(f32(ML), f32(ML)) for _ in range(ndl)]
-            b["qkv_s"] = [h16(ML, 3 * d) for _ in range(ndl)]
-            b["kv_c"] = [h16(M, 2 * d) for _ in range(ndl)]
-            b["lse_s"] = [f32(B, H, L) for _ in range(ndl)]
-            b["lse_c"] = [f32(B, H, L) for _ in range(ndl)]
-            b["pre_fd"] = [h16(ML, f) for _ in range(ndl)]
-            b["gfd"] = [h16(ML, f) for _ in range(ndl)]
-            if self.dec_lora:
-                for lin, G, rows in (("qkv", 3, ML), ("out", 1, ML), ("cq", 1, ML), ("ckv", 2, M), ("cout", 1, ML),
-                                     ("fc1", 1, ML), ("fc2", 1, ML)):
-                    b["ud_" + lin] = [h16(rows, G * r) for _ in range(ndl)]
-            b["xd"] = h16(ML, d)
-            b["st_d"] = (f32(ML), f32(ML))
-            b["logits"] = h16(ML, dims.vocab_pad)
-            b["row_loss"] = f32(ML)
-            b["dec_ids"] = torch.zeros(B, L, device=dev, dtype=torch.int64)
+        ndl = dims.dec_layers if train else 1
+        b["kv_c"] = [h16(M, 2 * d) for _ in range(ndl)]          # cross-attention K | V of the encoder rows, per decoder layer
+        if self.dec_lora:
+            b["ud_ckv"] = [h16(M, 2 * r) for _ in range(ndl)]
         if train:
             b["dh32"] = f32(M, d)
             b["dh16"] = h16(M, d)
@@ -502,8 +505,43 @@ class MegWhisperEngine:
                 b["du3"] = h16(M, 3 * r)
                 b["du"] = h16(M, r)
             if self.dec_lora:
-                b["ddu"] = h16(ML, 3 * r)
                 b["ddu_kv"] = h16(M, 2 * r)
+            b["dpre2"] = h16(B, S + 2, d)
+            b["dpre1"] = h16(B, T // 2 + 2, d)
+            b["dpre0"] = h16(B * T, d)
+        self._bufs[key] = b
+        return b
+
+    def _alloc_dec(self, B: int, L: int, train: bool):
+        dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
+        ML = B * L
+        dev = self.dev
+        h16 = lambda *s: torch.zeros(*s, device=dev, dtype=F16)  # noqa: E731
+        f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
+        nd = dims.dec_layers
+        ndl = nd if train else 1
+        b = {}
+        b["hd"] = [f32(ML, d) for _ in range((3 * nd + 1) if train else 2)]
+        for k in ("xs", "xc", "xm", "ao_s", "ao_c", "q_c"):
+            b[k] = [h16(ML, d) for _ in range(ndl)]
+        for k in ("st_s", "st_c", "st_m"):
+            b[k] = [(f32(ML), f32(ML)) for _ in range(ndl)]
+        b["qkv_s"] = [h16(ML, 3 * d) for _ in range(ndl)]
+        b["lse_s"] = [f32(B, H, L) for _ in range(ndl)]
+        b["lse_c"] = [f32(B, H, L) for _ in range(ndl)]
+        b["pre_fd"] = [h16(ML, f) for _ in range(ndl)]
+        b["gfd"] = [h16(ML, f) for _ in range(ndl)]
+        if self.dec_lora:
+            for lin, G in (("qkv", 3), ("out", 1), ("cq", 1), ("cout", 1), ("fc1", 1), ("fc2", 1)):
+                b["ud_" + lin] = [h16(ML, G * r) for _ in range(ndl)]
+        b["xd"] = h16(ML, d)
+        b["st_d"] = (f32(ML), f32(ML))
+        b["logits"] = h16(ML, dims.vocab_pad)
+        b["row_loss"] = f32(ML)
+        b["dec_ids"] = torch.zeros(B, L, device=dev, dtype=torch.int64)
+        if train:
+            if self.dec_lora:
+                b["ddu"] = h16(ML, 3 * r)
             b["ddh32"] = f32(ML, d)
             b["ddx32"] = f32(ML, d)
             b["ddh16"] = h16(ML, d)
@@ -513,16 +551,18 @@ class MegWhisperEngine:
             b["ddao"] = h16(ML, d)
             b["ddpre_f"] = h16(ML, f)
             b["ddelta"] = f32(B, H, L)
-            b["dpre2"] = h16(B, S + 2, d)
-            b["dpre1"] = h16(B, T // 2 + 2, d)
-            b["dpre0"] = h16(B * T, d)
-        self._bufs[key] = b
         return b
 
     # ------------------------------------------------------------------ helpers
+    def _gemm(self, **kw):
+        """ns_gemm with this engine's device-resident dropout counter attached"""
+        if kw.get("drop_p", 0.0) > 0.0 or kw.get("side_drop_p", 0.0) > 0.0:
+            kw["seed_dev"] = self.seed_ctr
+        ops.gemm(**kw)
+
     def _lin(self, x16, M, lin: _Lin, *, C16=None, ldc=None, G16=None, R32=None, H32=None, gelu=False,
              A2=None, lda2=0, K2=0, B2=None, ngroup=0, **side):
-        ops.gemm(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, **side,
+        self._gemm(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, **side,
                  A2=A2, am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
                  a2_ngroup=ngroup,
                  C16=C16, c16m=rowmap(ldc or lin.N) if C16 is not None else None,
@@ -533,7 +573,7 @@ class MegWhisperEngine:
     def _dgrad(self, dy16, M, lin: _Lin, out16, *, ldy=None, P16=None, A2=None, lda2=0, K2=0, B2=None,
                R32=None, H32=None, drop=False):
         """dx = dy * W  (+ du * A for LoRA), optional gelu' epilogue or fp32 accumulate."""
-        ops.gemm(A=dy16, am=rowmap(ldy or lin.N), K=lin.N, B=lin.wt, ldb=lin.N, M=M, N=lin.K,
+        self._gemm(A=dy16, am=rowmap(ldy or lin.N), K=lin.N, B=lin.wt, ldb=lin.N, M=M, N=lin.K,
                  A2=A2, am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
                  C16=out16, c16m=rowmap(lin.K) if out16 is not None else None,
                  P16=P16, p16m=rowmap(lin.K) if P16 is not None else None,
@@ -544,7 +584,7 @@ class MegWhisperEngine:
     def _ad_fwd(self, ad, x16, rows, lin: _Lin, u16, seed, **kw):
         """adapted linear, forward: u = drop(x) A^T / keep (all groups stacked), y = x W^T + b + u_g sB_g^T"""
         r, G, dp = self.r, ad["G"], self._drop_p()
-        ops.gemm(A=x16, am=rowmap(ad["kin"]), K=ad["kin"], B=ad["A"], ldb=ad["kin"], M=rows, N=G * r, C16=u16,
+        self._gemm(A=x16, am=rowmap(ad["kin"]), K=ad["kin"], B=ad["A"], ldb=ad["kin"], M=rows, N=G * r, C16=u16,
                  c16m=rowmap(G * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
         self._lin(x16, rows, lin, A2=u16, lda2=G * r, K2=r, B2=ad["sB"], ngroup=ad["nout"] if G > 1 else 0, **kw)
 
@@ -554,7 +594,7 @@ class MegWhisperEngine:
         r, G, nout, kin = self.r, ad["G"], ad["nout"], ad["kin"]
         ldy = G * nout
         for g in range(G):
-            ops.gemm(A=(dy16, g * nout), am=rowmap(ldy), K=nout, B=ad["sBT"][g], ldb=nout, M=rows, N=r, C16=(du16, g * r),
+            self._gemm(A=(dy16, g * nout), am=rowmap(ldy), K=nout, B=ad["sBT"][g], ldb=nout, M=rows, N=r, C16=(du16, g * r),
                      c16m=rowmap(G * r), alpha=self._drop_inv())
             self._wgrad_b((dy16, g * nout), ldy, (u16, g * r), G * r, rows, nout, ad["projs"][g], ad["alpha"][g],
                           ename=ad["site"] + ".lora_E", eoff=g * r)
@@ -583,7 +623,7 @@ class MegWhisperEngine:
         # with 256-row ranges a 32 x 512 gradient ran on 44 workgroups of four dependent steps each, 29 us)
         splits = max(1, min(Mred // (256 if Mred >= 16384 else 64), (target + tiles - 1) // tiles))
         bptr = self.G.data_ptr() + 4 * self.seg_off[bias_gname][0] if bias_gname else None
-        ops.gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
+        self._gemm(A=dy16, am=am or rowmap(ldy), K=Mred, B=x16, bm=bm or rowmap(ldx), M=No, N=Ko, C32=gptr,
                  ldc32=ldc or Ko, flags=NS_GEMM_TN | NS_GEMM_ATOMIC32 | (NS_GEMM_COLSUM_A if bias_gname else 0), splits=splits,
                  alpha=alpha, H32=bptr, drop_p=self._drop_p() if drop else 0.0, drop_seed=self._cur_seed if drop else 0)
 
@@ -617,22 +657,22 @@ class MegWhisperEngine:
         if self.frontend == "base":
             c0, c1 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"]
             # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
-            ops.gemm(A=xin, am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d,
+            self._gemm(A=xin, am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d, k_alg=3 * dims.ch,
                      bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d),
                      g16m=rowmap(d, T, (T + 2) * d), flags=GELU_FWD)
             # conv1.2 (k3,s2) + the encoder's outer GELU
-            ops.gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
+            self._gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
                      bias=pb("conv1.2"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
                      g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
         else:
             # 'replace': one stride-2 conv over the packed signal + the encoder's outer GELU
             cr = self.conv_ops["conv1"]
-            ops.gemm(A=xin, am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
+            self._gemm(A=xin, am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
                      bias=pb("conv1"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
                      g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
         # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
         h = b["h"]
-        ops.gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
+        self._gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
                  bias=pb("conv2"), C16=b["pre2"] if train else None, c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
                  pos_rows=S, flags=GELU_FWD)
         dp = self._drop_p()
@@ -649,7 +689,7 @@ class MegWhisperEngine:
             seed = self._layer_seed(i)
             ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
             if r:
-                ops.gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
+                self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
                          c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
                 self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j], A2=b["uqkv"][j], lda2=3 * r, K2=r, B2=lo["sBqkv"],
                           ngroup=d)
@@ -659,14 +699,14 @@ class MegWhisperEngine:
             ops.attn_fwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][j], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
                          ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j])
             if r:
-                ops.gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
+                self._gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 1)
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"])
             else:
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid)
             ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
             if r:
-                ops.gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
+                self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
                 side = train and "u2_slabs" in b and not self.no_side_u2
                 sk = dict(side_B=lo["fc2_A"], side_ldb=f, side_n=r, side_out=b["u2_slabs"], side_drop_p=dp,
@@ -676,7 +716,7 @@ class MegWhisperEngine:
                 if side:   # u2 = drop(gf) A^T / keep from the slabs the GELU epilogue left (no second pass over gf)
                     ops.gemm_side_reduce(b["u2_slabs"], f // 256, M, self._drop_inv(), b["u2"][j], r)
                 else:
-                    ops.gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
+                    self._gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
                              flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 3)
                 self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
             else:
@@ -737,7 +777,7 @@ class MegWhisperEngine:
         b["hd_last"] = hl
         ops.layernorm_fwd(hl, *self.dec_ln, b["xd"], *b["st_d"], ML, d)
         Vp = dims.vocab_pad
-        ops.gemm(A=b["xd"], am=rowmap(d), K=d, B=self.E16, ldb=d, M=ML, N=Vp, C16=b["logits"], c16m=rowmap(Vp))
+        self._gemm(A=b["xd"], am=rowmap(d), K=d, B=self.E16, ldb=d, M=ML, N=Vp, C16=b["logits"], c16m=rowmap(Vp))
         return b["logits"]
 
     @staticmethod
@@ -775,7 +815,7 @@ class MegWhisperEngine:
                 self.reg_dev.zero_()
                 ops.orth_reg(self._orth_table, self._n_orth, self.lora.orth_reg_weight / self._n_orth,
                              self.loss_scale_dev, self.reg_dev)
-                self.total_loss_dev = self.loss_dev + self.reg_dev
+                torch.add(self.loss_dev, self.reg_dev, out=self.total_loss_dev)     # static buffer: graph replays write it too
                 loss = self.total_loss_dev
         return loss, logits.view(B, L, dims.vocab_pad)[:, :, :dims.vocab]
 
@@ -796,11 +836,11 @@ class MegWhisperEngine:
         splits = max(1, min(64, Vp // 2048, -(-1024 // tiles)))
         if splits > 1:
             b["ddx32"].zero_()
-            ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C32=b["ddx32"], ldc32=d, splits=splits)
+            self._gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C32=b["ddx32"], ldc32=d, splits=splits)
             ops.layernorm_bwd(b["ddx32"], True, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
                               b["ddh16"], ML, d)
         else:
-            ops.gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C16=b["ddx16"], c16m=rowmap(d))
+            self._gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C16=b["ddx16"], c16m=rowmap(d))
             ops.layernorm_bwd(b["ddx16"], False, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
                               b["ddh16"], ML, d)
         first_enc = True
@@ -924,7 +964,7 @@ class MegWhisperEngine:
             return
         tmp = self._gbf[:N * r]
         tmp.zero_()
-        ops.gemm(A=dy16, am=rowmap(ldy), K=Mred, B=u16, bm=rowmap(ldu), M=N, N=r, C32=tmp, ldc32=r,
+        self._gemm(A=dy16, am=rowmap(ldy), K=Mred, B=u16, bm=rowmap(ldu), M=N, N=r, C32=tmp, ldc32=r,
                  flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(Mred // 256, -(-384 // ((N + 127) // 128)))))
         en = ename or key + ".lora_E"
         ops.adalora_fold_grads(tmp, self.pview(key + ".lora_B"), (self.pview(en), eoff), self.gview(key + ".lora_B"),
@@ -962,7 +1002,7 @@ class MegWhisperEngine:
                                            (self.gview(en), eoff), N, r, alphas[g])
             return
         for g, k in enumerate(keys):
-            ops.gemm(A=(dy16, g * N) if G > 1 else dy16, am=rowmap(ldy), K=N, B=sBT[g], ldb=N, M=M, N=r,
+            self._gemm(A=(dy16, g * N) if G > 1 else dy16, am=rowmap(ldy), K=N, B=sBT[g], ldb=N, M=M, N=r,
                      C16=(du16, g * r) if G > 1 else du16, c16m=rowmap(G * r), alpha=self._drop_inv())
             en, eoff = enames[g] if enames else (None, 0)
             self._wgrad_b((dy16, g * N) if G > 1 else dy16, ldy, (u16, g * r) if G > 1 else u16, G * r, M, N, k, alphas[g],
@@ -993,9 +1033,9 @@ class MegWhisperEngine:
         # gelu'(pre1) is applied in the epilogue; results land directly in the halo layout of d(pre1)
         ev = rowmap(2 * d, S, T2 * d)
         evh = rowmap(2 * d, S, (T2 + 2) * d)
-        ops.gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=(b["dpre1"], d), c16m=evh, P16=b["pre1"],
+        self._gemm(A=dp2, am=hal2, K=d, B=c2["we"], ldb=d, M=M, N=d, C16=(b["dpre1"], d), c16m=evh, P16=b["pre1"],
                  p16m=ev, flags=NS_GEMM_MUL_P16)
-        ops.gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dpre1"], 2 * d), c16m=evh,
+        self._gemm(A=dp2, am=hal2, K=2 * d, B=c2["wo"], ldb=2 * d, M=M, N=d, C16=(b["dpre1"], 2 * d), c16m=evh,
                  P16=(b["pre1"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         dp1 = (b["dpre1"], d)
         hal1 = rowmap(d, T2, (T2 + 2) * d)
@@ -1007,9 +1047,9 @@ class MegWhisperEngine:
         self._wgrad(dp1, 0, b["g0"], 0, B * T2, d, 3 * d, "model.encoder.conv1.2.wp", am=hal1,
                     bm=rowmap(2 * d, T2, (T + 2) * d), bias_gname="model.encoder.conv1.2.bias")
         ev = rowmap(2 * d, T2, T * d)
-        ops.gemm(A=dp1, am=hal1, K=d, B=c1["we"], ldb=d, M=B * T2, N=d, C16=b["dpre0"], c16m=ev, P16=b["pre0"], p16m=ev,
+        self._gemm(A=dp1, am=hal1, K=d, B=c1["we"], ldb=d, M=B * T2, N=d, C16=b["dpre0"], c16m=ev, P16=b["pre0"], p16m=ev,
                  flags=NS_GEMM_MUL_P16)
-        ops.gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
+        self._gemm(A=dp1, am=hal1, K=2 * d, B=c1["wo"], ldb=2 * d, M=B * T2, N=d, C16=(b["dpre0"], d), c16m=ev,
                  P16=(b["pre0"], d), p16m=ev, flags=NS_GEMM_MUL_P16)
         self._wgrad(b["dpre0"], 0, b["xin_cur"], 0, B * T, d, 3 * Cp, "model.encoder.conv1.0.wp", am=rowmap(d, T, T * d),
                     bm=rowmap(Cp, T, (T + 2) * Cp), bias_gname="model.encoder.conv1.0.bias")
@@ -1027,10 +1067,115 @@ class MegWhisperEngine:
                        self.found_inf_dev, self.loss_scale_dev if tc.fp16_scaler else None,
                        self.growth_dev if tc.fp16_scaler else None)
         self.refresh_operands()
-        self.drop_seed += 1
+        self.seed_ctr.add_(1)       # next step, next dropout masks (device-side: see _init_opt_state)
 
     def train_step(self, x32, labels, on_ready=None, reduce_fn=None):
-        """forward + backward (+ optional gradient reduction) + optimizer; returns the device loss scalar."""
+        """forward + backward (+ optional gradient reduction) + optimizer; returns the device loss scalar.
+
+        On a GPU the step is captured once per (batch shape, label length, input buffer) in hipGraphs and replayed: a step
+        is ~380 launches whose enqueueing costs ~17 ms of Python / ctypes, more than the 15 ms a step may take at
+        north_star's 40 % target, and under data parallelism eight such interpreters share one host.  Nothing in a step
+        depends on the host: optimizer state, loss scale, schedule and the dropout counter live on the device.  With a
+        gradient exchange (`on_ready` / `reduce_fn`: dp.GradReducer) the capture is CUT at every on_ready point, so the
+        RCCL chunks are launched eagerly on their side stream between two replays exactly where the eager step launches
+        them.  The first step of a shape runs eagerly (lazy allocations), the second is captured."""
+        if not self._graph_usable(x32):
+            return self._train_step_eager(x32, labels, on_ready, reduce_fn)
+        packed = isinstance(x32, PackedSignal)
+        xkey = x32.xin.data_ptr() if packed else x32.data_ptr()
+        key = (tuple(x32.shape), tuple(labels.shape), xkey, on_ready is not None)
+        g = self._graphs.get(key)
+        if g is None:
+            warm = (tuple(x32.shape), tuple(labels.shape))
+            if warm not in self._graph_warm:
+                self._graph_warm.add(warm)
+                return self._train_step_eager(x32, labels, on_ready, reduce_fn)
+            try:
+                g = self._capture_step(x32, labels, on_ready is not None)
+            except RuntimeError as e:
+                # another host thread outside this package's capture lock (e.g. torch's pin-memory thread) can invalidate a
+                # capture on HIP: nothing has executed, so run this step eagerly and try again later, a bounded number of times
+                torch.cuda.synchronize()
+                self._graph_failures += 1
+                if self._graph_failures >= 3:
+                    self.use_graph = False
+                import warnings
+                warnings.warn(f"train_step: hipGraph capture failed ({str(e).splitlines()[0][:120]}); eager step "
+                              f"({'graphs disabled' if not self.use_graph else 'will retry'})")
+                return self._train_step_eager(x32, labels, on_ready, reduce_fn)
+            if len(self._graphs) >= self.graph_cache:        # label lengths / staging slots seen long ago: drop the oldest
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = g
+        if packed:
+            x32.acquire()            # the copy stream's event: waited for eagerly, never inside a capture
+        g["labels"].copy_(labels, non_blocking=True)
+        self.training_mode = True
+        self._b = g["b"]
+        for seg, hook in zip(g["segs"], g["hooks"]):
+            seg.replay()
+            if hook is not None:
+                if hook == "reduce":
+                    if reduce_fn is not None:
+                        reduce_fn()
+                elif on_ready is not None:
+                    on_ready(*hook)
+        return self.loss_dev if not self.adalora else self.total_loss_dev
+
+    def _graph_usable(self, x32):
+        if not (self.use_graph and self.dev.type == "cuda"):
+            return False
+        # the bench's instrumentation (events around every GEMM / section marks) belongs to eager steps
+        return ops.GEMM_PROFILE is None and getattr(self, "section_events", None) is None
+
+    def _capture_step(self, x32, labels, cut: bool):
+        """Capture one training step.  Nothing executes during capture: the caller replays the segments afterwards.
+        cut=True ends a segment at every on_ready point of backward() and before the optimizer (hooks: (lo, hi) of the
+        gradient chunk that is final there, "reduce" = the exchange must have completed)."""
+        if isinstance(x32, PackedSignal):
+            x32.acquire()
+        lab = labels.clone()
+        torch.cuda.synchronize()
+        segs, hooks = [], []
+        state = {"g": None, "ctx": None}
+        pool = torch.cuda.graph_pool_handle()       # one private pool for all segments of this step
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            # thread-local capture mode: the data feed's loader thread issues copies on its own stream meanwhile
+            ctx = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local")
+            ctx.__enter__()
+            state["g"], state["ctx"] = g, ctx
+
+        def end(hook):
+            ctx, state["ctx"] = state["ctx"], None
+            ctx.__exit__(None, None, None)          # raises when the capture was invalidated: the caller falls back to eager
+            segs.append(state["g"])
+            hooks.append(hook)
+
+        def cut_here(lo, hi):
+            end((lo, hi))
+            begin()
+        with GPU_CAPTURE_LOCK:      # no other thread of this package touches the GPU API while the capture is open
+            begin()
+            try:
+                self.zero_grad()
+                self.forward(x32, lab, train=True, compute_grad=True)
+                self.backward(cut_here if cut else None)
+                if cut:
+                    end("reduce")
+                    begin()
+                self.optimizer_step()
+                end(None)
+            except BaseException:
+                if state["ctx"] is not None:        # close the open capture before the error travels on
+                    try:
+                        state["ctx"].__exit__(None, None, None)
+                    except Exception:
+                        pass
+                raise
+        return {"segs": segs, "hooks": hooks, "labels": lab, "b": self._b}
+
+    def _train_step_eager(self, x32, labels, on_ready=None, reduce_fn=None):
         self.zero_grad()
         loss, _ = self.forward(x32, labels, train=True, compute_grad=True)
         self.backward(on_ready)

@@ -25,7 +25,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
-from .lib import NS_FEED_F16, NS_FEED_F32, NS_FEED_F64
+from .lib import GPU_CAPTURE_LOCK, NS_FEED_F16, NS_FEED_F32, NS_FEED_F64
 
 _DTYPES = {"<f8": (NS_FEED_F64, 8), "<f4": (NS_FEED_F32, 4), "<f2": (NS_FEED_F16, 2)}
 _ALIGN = 256
@@ -262,14 +262,15 @@ class SignalFeed:
         plans = list(self.pool.map(lambda r: plan_read(r, self.T), raws))
         offs, used = layout_batch(plans)
         s = self._slot()
-        self._fit(s, B, max(used, 1))
+        with GPU_CAPTURE_LOCK:              # never synchronize / allocate while another thread has a graph capture open
+            self._fit(s, B, max(used, 1))
         if s.used_once:
             s.h2d_done.synchronize()        # the pinned block is about to be overwritten by host threads
         host = memoryview(s.pinned.numpy())
         list(self.pool.map(lambda po: _fill(po[0], host[po[1]:po[1] + po[0].nbytes]), zip(plans, offs)))
         tab = item_table(plans, offs, s.staging.data_ptr())
         s.items_host[:B * ITEM_BYTES].copy_(torch.from_numpy(tab.view(np.uint8).reshape(-1)))
-        with torch.cuda.stream(self.stream):
+        with GPU_CAPTURE_LOCK, torch.cuda.stream(self.stream):
             if s.used_once:
                 self.stream.wait_event(s.free)      # the step that read this slot's previous batch has finished
             if used:

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .lib import GPU_CAPTURE_LOCK
 from .ops import rowmap
 
 F16, F32 = torch.float16, torch.float32
@@ -242,13 +243,14 @@ class Generator:
                         torch.cuda.synchronize()
                         for _ in range(2):
                             gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                            # thread-local capture mode: other host threads (the data feed's loader thread issues copies
-                            # and a kernel on its own stream) must not invalidate this capture
-                            with torch.cuda.graph(gs, capture_error_mode="thread_local"):
-                                select(cur, ctr)
-                            with torch.cuda.graph(gt, capture_error_mode="thread_local"):
-                                step(next_tok, cur, parent, ctr)
-                                ctr.add_(1)
+                            # thread-local capture mode + the package's capture lock: other host threads (the data feed's
+                            # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
+                            with GPU_CAPTURE_LOCK:
+                                with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                                    select(cur, ctr)
+                                with torch.cuda.graph(gt, capture_error_mode="thread_local"):
+                                    step(next_tok, cur, parent, ctr)
+                                    ctr.add_(1)
                             graphs.append((gs, gt))
                 else:
                     graphs[(n_sel - 2) & 1][1].replay()

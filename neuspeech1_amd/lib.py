@@ -17,6 +17,16 @@ class NeuSpeechHipError(RuntimeError):
     pass
 
 
+# Held while a hipGraph capture is open (engine.train_step, generate's decode loop) and by every other host thread of this
+# package around its GPU API calls (the data feed's loader thread: device synchronize, pinned / device allocations, copies).
+# HIP invalidates an open capture when another thread synchronizes the device or allocates meanwhile, thread-local capture
+# mode notwithstanding (seen on ROCm 7.0/7.2: hipErrorStreamCaptureInvalidated at the first captured launch).
+import threading  # noqa: E402
+GPU_CAPTURE_LOCK = threading.RLock()
+
+ABI_VERSION = 2      # ns_version() of the library this binding was written against (ns_gemm_desc.seed_dev)
+
+
 class RowMap(C.Structure):
     _fields_ = [("seg_stride", C.c_int64), ("seg_rows", C.c_int32), ("ld", C.c_int32)]
 
@@ -43,6 +53,7 @@ class GemmDesc(C.Structure):
         ("side_B", C.c_void_p), ("side_ldb", C.c_int32), ("side_n", C.c_int32),
         ("side_out", C.c_void_p),
         ("side_drop_p", C.c_float), ("side_drop_seed", C.c_uint32),
+        ("seed_dev", C.c_void_p),
     ]
 
 
@@ -226,7 +237,7 @@ def load() -> C.CDLL:
             raise NeuSpeechHipError(f"libneuspeech_hip.so lacks symbol {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ns_version() != 1:
+    if lib.ns_version() != ABI_VERSION:
         raise NeuSpeechHipError(f"ABI version mismatch: {lib.ns_version()}")
     _lib = lib
     return lib

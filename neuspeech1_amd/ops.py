@@ -49,10 +49,13 @@ GEMM_PROFILE = None   # set to a list by bench.py to time every GEMM launch with
 def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
          bias=None, C16=None, c16m=None, G16=None, g16m=None, P16=None, p16m=None, R32=None, H32=None, h32m=None,
          pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0,
-         side_B=None, side_ldb=0, side_n=0, side_out=None, side_drop_p=0.0, side_drop_seed=0):
+         side_B=None, side_ldb=0, side_n=0, side_out=None, side_drop_p=0.0, side_drop_seed=0, k_alg=None, seed_dev=None):
+    """k_alg: the ALGORITHMIC reduction length where K carries padding (the first conv: 3 x ch against 3 x ch_pad);
+    only the bench's FLOP count reads it"""
     d = GemmDesc()
     d.side_B, d.side_ldb, d.side_n, d.side_out = ptr(side_B), side_ldb, side_n, ptr(side_out)
     d.side_drop_p, d.side_drop_seed = side_drop_p, side_drop_seed
+    d.seed_dev = ptr(seed_dev)
     d.A, d.am, d.K = ptr(A), am, K
     d.B = ptr(B)
     d.bm = bm if bm is not None else rowmap(ldb)
@@ -82,7 +85,7 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
     e1.record(torch.cuda.current_stream())
-    GEMM_PROFILE.append((kind, 2.0 * M * N * (K + K2 + (side_n if side_B is not None else 0)), e0, e1))   # side product: 2 M N side_n more
+    GEMM_PROFILE.append((kind, 2.0 * M * N * ((k_alg or K) + K2 + (side_n if side_B is not None else 0)), e0, e1))   # side product: 2 M N side_n more
 
 
 def gemm_side_supported(M: int, N: int, K: int) -> bool:
@@ -302,12 +305,15 @@ def make_orth_jobs(jobs, device):
 
 
 _orth_ws = {}
+_retired_ws = []   # outgrown workspaces stay allocated: graphs captured while they were current replay with their address
 
 
 def orth_reg(table, njobs, weight_over_num, loss_scale_dev, reg_out_dev):
     need = L.load().ns_orth_reg_workspace_bytes(njobs)
     ws = _orth_ws.get(reg_out_dev.device)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _retired_ws.append(ws)      # a captured training step (hipGraph) may still hold its address
         ws = torch.empty(need, device=reg_out_dev.device, dtype=torch.uint8)
         _orth_ws[reg_out_dev.device] = ws
     L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), ptr(ws), ws.numel(),
@@ -330,6 +336,8 @@ def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du
         need = L.load().ns_lora_bwd_workspace_bytes(M, N, len(sBT), splits)
         ws = _lora_ws.get(du.device)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                _retired_ws.append(ws)
             ws = torch.empty(need, device=du.device, dtype=torch.uint8)
             _lora_ws[du.device] = ws
         d.workspace, d.workspace_bytes = ptr(ws), ws.numel()

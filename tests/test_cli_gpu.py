@@ -471,6 +471,11 @@ def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
     # all-reduce that backward did not hide (the optimizer stream's wait for the side stream)
     assert d["dp"]["allreduce_bytes_per_step"] > 1e6 and d["dp"]["exposed_allreduce_ms_per_step"] >= 0.0
     assert d["dp"]["exposed_allreduce_ms_per_step"] < d["ms_per_step"]
+    # the collective's own time on the side stream (events around every chunk) against the part the optimizer waited for:
+    # exposed < total means the chunks launched from backward's on_ready points really ran beside backward
+    assert d["dp"]["allreduce_ms_per_step"] > 0.0
+    assert d["dp"]["exposed_allreduce_ms_per_step"] < d["dp"]["allreduce_ms_per_step"], d["dp"]
+    assert len(d["dp"]["rank_ms_per_step"]) == 2 and d["dp"]["rank_skew_ms"] >= 0.0
     assert 0.0 < d["config"]["encoder_fwd_bwd_mfma_frac"] < 1.0
 
 
