@@ -276,9 +276,15 @@ typedef struct {
   int32_t B, H, Lq, Lk, head_dim;
   int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int32_t causal;
+  /* backward only (ABI 2): with a workspace of ns_attn_bwd_workspace_bytes(...) bytes (> 0 for unmasked attention over
+     >= 256 queries and keys) the backward runs in ONE pass -- S and dP formed once, dQ summed over the key sweeps of a
+     (batch, head) in this caller-owned fp32 scratch, no atomics (csrc/ns_attn_bwd1.hip) -- instead of the dQ pass +
+     dK/dV pass, which each recompute S and dP.  NULL / 0 keeps the two-pass kernels. */
+  void* workspace; size_t workspace_bytes;
 } ns_attn_desc;
 int ns_attn_fwd(const ns_attn_desc* d, void* stream);
 int ns_attn_bwd(const ns_attn_desc* d, void* stream);   /* writes dQ, dK, dV and Delta */
+size_t ns_attn_bwd_workspace_bytes(int B, int H, int Lq, int Lk, int causal);   /* 0: the one-pass form does not apply */
 
 /* ------------------------------------------------------------------------
  * Cross-entropy on fp16 logits (rows x ldv, first V columns valid), labels

@@ -503,10 +503,14 @@ extern "C" int ns_attn_fwd(const ns_attn_desc* d, void* stream) {
   return NS_OK;
 }
 
+int ns_attn_bwd1_launch(const ns_attn_desc* d, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 extern "C" int ns_attn_bwd(const ns_attn_desc* d, void* stream) {
   int rc = check_desc(d, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (d->workspace && ns_attn_bwd_workspace_bytes(d->B, d->H, d->Lq, d->Lk, d->causal) > 0)
+    return ns_attn_bwd1_launch(d, d->workspace, d->workspace_bytes, st);   // one pass: csrc/ns_attn_bwd1.hip
   dim3 gq((d->Lq + 127) / 128, d->H, d->B), gk((d->Lk + 127) / 128, d->H, d->B);
   if (d->causal) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), 0, st, *d);

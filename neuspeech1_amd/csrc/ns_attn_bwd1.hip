@@ -1,0 +1,344 @@
+// Attention backward in ONE pass (head_dim 64, no mask): dQ, dK, dV from a single sweep structure that forms the five
+// products S, dP, dV^T, dK^T, dQ once each, where ns_attn.hip's two kernels recompute S and dP (seven products, two
+// exponentials per score).  Replaces the autograd backward of HF:modeling_whisper.py:215-238 for the encoder's
+// self-attention (Lq = Lk = 1500), where the backward is ~22 % of a training step.
+//
+// Structure.  One workgroup (8 waves) per (batch, head).  It walks the keys in SWEEPS of 256 (32 keys per wave, the key
+// on the MFMA lane as in attn_bwd_dkv_kernel: K / V fragments and the dK^T / dV^T accumulators live in registers for the
+// whole sweep) and, inside a sweep, the queries in steps of 64:
+//     S^T-orientation:  st[q][key] = Q K^T - lse,  dp[q][key] = dO V^T - delta      (row constants ride in as the
+//                       initial accumulators), P = exp2(log2e st) with the scale applied in fp32, dS = P dp
+//     dV^T += dO^T P,  dK^T += Q^T dS            (the accumulators are the B operands in place)
+//     dQ[64 q][64 d] = dS[64 q][256 keys] K[256 keys][64 d]  sums over the LANE index of dS, so dS crosses LDS once:
+//                       every lane stores its 4-query pieces into a [key][query] image and the eight waves read it back
+//                       transposed (ds_read_b64_tr_b16) as the A operand of v_mfma_f32_16x16x32_f16, each wave owning a
+//                       (32 query x 16 d) part of the tile with its K^T fragments in registers for the whole sweep.
+// The dQ partial of a sweep is ADDED to the previous sweeps' sum in a workgroup-private fp32 scratch (same lane, same
+// address in every sweep: a plain load / add / store, no atomics, no cross-workgroup reduction, bitwise reproducible); the
+// last sweep rounds the sum to fp16 straight into dQ.  Per (batch, head) the scratch is 384 KiB (Lq x 64 floats), written
+// and re-read sweep after sweep through L2 / Infinity Cache -- against 1.18 GB of fp32 atomics or slabs per layer for a
+// grid of 256-key blocks.
+//
+// One barrier per step: tiles, dS images and row constants are double-buffered; iteration t forms the scores of step t and
+// the dQ product of step t - 1.  Every vector-memory operation of the loop sits in the tail of a half-step, ordered
+// consume -> store -> request (gfx950 has ONE in-order counter for loads and stores and hipcc waits vmcnt(0) around
+// branches): a request is never waited for in the half-step that issued it.
+//
+// Measured (B 64, H 8, S 1500, random data, tools/probe/attn_bwd_ab.py): 1.13-1.14 ms against 1.19-1.22 ms for the two
+// passes, and 1.6x (|S| ~ 10) to 6x (|S| ~ 40) closer to fp32 autograd, because the recomputed P is the forward's P (the
+// two-pass kernels fold log2(e) into an fp16 operand).  The waves are parked half of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES
+// = 0.49 against 0.24 for the two-pass kernels, which run two independent 4-wave workgroups per CU): eight waves in
+// lock-step behind one barrier expose every LDS round trip; issued instructions are 26 % fewer.
+#include "ns_common.h"
+
+namespace {
+
+constexpr int D = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KB = 256;      // keys per sweep (32 per wave)
+constexpr int QT = 64;       // queries per step
+constexpr int NT = 512;
+
+// [rows 64][64 halfs] tile image shared by the row reads and the transposed reads (same as ns_attn.hip)
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return 1024 * (row >> 3) + 512 * (chunk >> 2) + 64 * (row & 7) + 16 * ((chunk & 3) ^ ((row >> 2) & 3));
+}
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) short4v lds_s4;
+
+__device__ __forceinline__ half8 tr_frag8(const char* tile, int rbase, int cb, int lane) {
+  const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+  const int row = rbase + 4 * (g >> 1) + q;
+  const int ch = (cb >> 3) + 2 * (g & 1) + (p >> 1);
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + lds_off(row, ch) + 8 * (p & 1)));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + lds_off(row + 8, ch) + 8 * (p & 1)));
+  const short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8, r);
+}
+__device__ __forceinline__ half8 cvt8(const f32x16& x, int base) {
+  half8 h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = (half_t)x[base + j];
+  return h;
+}
+
+// dS image [key 0..255][query 0..63] fp16, 128-B rows, addressed in 8-byte granules (4 queries): granule qg of key row k
+// sits at 128 k + 8 (qg ^ s(k)).  s is a bijection on k & 15, so the 16 lanes of a ds_write_b64 group (16 consecutive keys,
+// same qg) hit 16 different bank pairs; its bits 2..3 are key bits 1 and 3, so the eight 4-key row pieces a 32-lane half
+// reads transposed (keys {0..3} and {8..11} of a 16-key group, or {4..7} and {12..15}) fall into disjoint bank windows.
+__device__ __forceinline__ int ds_swz(int k) { return ((k >> 1) & 1) << 2 | ((k >> 3) & 1) << 3 | (k & 1) | ((k >> 2) & 1) << 1; }
+__device__ __forceinline__ int ds_off(int k, int qg) { return 128 * k + 8 * (qg ^ ds_swz(k)); }
+
+// delta[b][h][q] = sum_d dO[q][d] O[q][d]   (8 lanes per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const ns_attn_desc p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long item = t >> 3;                 // (row, head)
+  const int part = (int)(t & 7);
+  const long long rows = (long long)p.B * p.Lq;
+  const bool ok = item < rows * p.H;
+  const long long row = ok ? item / p.H : 0;
+  const int h = ok ? (int)(item % p.H) : 0;
+  float s = 0.f;
+  if (ok) {
+    const half8 a = *(const half8*)((const half_t*)p.dO + row * p.lddo + h * D + 8 * part);
+    const half8 o = *(const half8*)((const half_t*)p.O + row * p.ldo + h * D + 8 * part);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)o[j];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (ok && part == 0) {
+    const long long b = row / p.Lq, q = row % p.Lq;
+    p.Delta[(b * p.H + h) * p.Lq + q] = s;
+  }
+}
+
+
+struct I0_ { static constexpr int value = 0; };
+struct I1_ { static constexpr int value = 1; };
+struct T_ { static constexpr bool value = true; };
+struct F_ { static constexpr bool value = false; };
+
+// One sweep (256 keys) of one (batch, head).  first: no earlier partial dQ to add; last: the sum leaves as fp16 dQ.
+__device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4* scr, int kb0, int b, int h, int nsteps,
+                                      const bool first, const bool last) {
+  char* const DS0 = smem + 32768;
+  float* const rc0 = (float*)(smem + 32768 + 2 * KB * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const half_t* dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
+  const float* LSE = p.LSE + ((long long)b * p.H + h) * p.Lq;
+  const float* Delta = p.Delta + ((long long)b * p.H + h) * p.Lq;
+  const int qh = wave & 1, dq = wave >> 1;
+  const int srow = tid >> 3, sch = tid & 7;
+  const int s_off = lds_off(srow, sch);
+
+  const int key = kb0 + wave * 32 + lr;
+  const int krow = min(key, p.Lk - 1);
+  const bool keyok = key < p.Lk;
+  half8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
+    vf[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
+  }
+  // K^T fragments of the dQ product (B operand of 16x16x32: lane n = d column, 8 consecutive keys per k-group): the sweep's
+  // K rows go through LDS once (coalesced 16-B loads into the second dS image, which no step has touched yet) and come
+  // back transposed.  Keys past Lk (last sweep) enter as ZERO rows: whatever their dS holds, they add nothing to dQ.
+  // (Fetched straight from global memory these are 64 two-byte loads per lane, which hipcc serialised behind one
+  // s_waitcnt vmcnt(0) each: ~0.4 ms per launch.)
+  half8 ktf[8];
+  {
+    char* const KT = DS0 + KB * 128;
+    __syncthreads();            // the previous sweep's last dQ reads of this image are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = tid + NT * i;             // 2048 pieces of 16 B: key = piece >> 3, chunk = piece & 7
+      const int kk = kb0 + (piece >> 3);
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (kk < p.Lk) v = *(const uint4*)(K + (long long)kk * p.ldk + (piece & 7) * 8);
+      *(uint4*)(KT + piece * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = 32 * ks + 8 * lg + (l15 >> 2);
+      const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(KT + 128 * k0 + 32 * dq + 8 * (l15 & 3)));
+      const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(KT + 128 * (k0 + 4) + 32 * dq + 8 * (l15 & 3)));
+      const short8v a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      ktf[ks] = __builtin_bit_cast(half8, a);
+    }
+  }
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[t][r] = 0.f; dvt[t][r] = 0.f; }
+
+  uint4 qreg, dreg;
+  float lse_r = 0.f, del_r = 0.f;
+  auto load_tile = [&](int q0) __attribute__((always_inline)) {
+    const long long rr = min(q0 + srow, p.Lq - 1);
+    qreg = *(const uint4*)(Q + rr * p.ldq + sch * 8);
+    dreg = *(const uint4*)(dO + rr * p.lddo + sch * 8);
+    if (tid < 64) { const int qq = min(q0 + tid, p.Lq - 1); lse_r = LSE[qq]; del_r = Delta[qq]; }
+  };
+  auto store_tile = [&](int buf, int q0) __attribute__((always_inline)) {
+    *(uint4*)(smem + buf * 16384 + s_off) = qreg;
+    *(uint4*)(smem + buf * 16384 + 8192 + s_off) = dreg;
+    if (tid < 64) {
+      const bool qok = q0 + tid < p.Lq;
+      rc0[buf * 128 + tid] = qok ? -lse_r : -INFINITY;      // queries past Lq: P = exp2(-inf) = 0, so dS = 0 too
+      rc0[buf * 128 + 64 + tid] = -del_r;
+    }
+  };
+  float4 nrun0 = {0.f, 0.f, 0.f, 0.f}, nrun1 = {0.f, 0.f, 0.f, 0.f};    // running dQ sums in flight (see the step's tail)
+  // iteration t: scores of step t (HB) and the dQ product of step t - 1 (HA)
+  auto step = [&](auto HA_, auto HB_, int t) __attribute__((always_inline)) {
+    constexpr bool HA = decltype(HA_)::value, HB = decltype(HB_)::value;
+    const int q0 = t * QT, cur = t & 1;
+    __syncthreads();
+    const char* const Qs = smem + cur * 16384;
+    const char* const dOs = Qs + 8192;
+    char* const DSw = DS0 + cur * (KB * 128);
+    const char* const DSr = DS0 + (cur ^ 1) * (KB * 128);
+    const float* const lse_s = rc0 + cur * 128;
+    const float* const del_s = lse_s + 64;
+    // the two 32-query halves of the step, as two straight-line copies (static registers for the values in flight, exact
+    // waits) kept apart by a scheduling fence: interleaved by hipcc they need both halves' scores live at once and spill
+    auto half = [&](auto QT_) __attribute__((always_inline)) {
+      constexpr int qt = decltype(QT_)::value;
+      f32x16 st, dp;
+      if constexpr (HB) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 nl = *(const float4*)(lse_s + qt * 32 + 8 * g + 4 * lh);
+          const float4 nd = *(const float4*)(del_s + qt * 32 + 8 * g + 4 * lh);
+          st[4 * g + 0] = nl.x; st[4 * g + 1] = nl.y; st[4 * g + 2] = nl.z; st[4 * g + 3] = nl.w;
+          dp[4 * g + 0] = nd.x; dp[4 * g + 1] = nd.y; dp[4 * g + 2] = nd.z; dp[4 * g + 3] = nd.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const half8 aq = *(const half8*)(Qs + lds_off(qt * 32 + lr, 2 * s + lh));
+          const half8 ad = *(const half8*)(dOs + lds_off(qt * 32 + lr, 2 * s + lh));
+          st = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, kf[s], st, 0, 0, 0);   // S[q][key] - lse[q]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, vf[s], dp, 0, 0, 0);   // dP[q][key] - delta[q]
+        }
+      }
+      // ---- dQ of the PREVIOUS step, 16-row tile mt = qt of this wave's part: rows 32 qh + 16 mt + (0..15), columns
+      // 16 dq + (0..15), summed over the sweep's 256 keys; added to the earlier sweeps' sum (same lane, same address)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (HA) {
+        const int qg = 4 * (2 * qh + qt) + (l15 & 3);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const int k0 = 32 * ks + 8 * lg + (l15 >> 2);
+          const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(DSr + ds_off(k0, qg)));
+          const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(DSr + ds_off(k0 + 4, qg)));
+          const short8v a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), ktf[ks], acc, 0, 0, 0);
+        }
+      }
+      if constexpr (HB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[r] * LOG2E);   // the scale stays in fp32: P is the forward's P
+          st[r] = pv;
+          dp[r] = pv * dp[r];       // dS
+        }
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half8 pb = cvt8(st, 8 * s2);
+          const half8 dsb = cvt8(dp, 8 * s2);
+          const int sg = qt * 2 + s2;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const half8 a1 = tr_frag8(dOs, 16 * sg, dt * 32, lane);
+            const half8 a2 = tr_frag8(Qs, 16 * sg, dt * 32, lane);
+            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb, dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, dsb, dkt[dt], 0, 0, 0);
+          }
+        }
+          // dS -> the [key][query] image: register 4g .. 4g+3 = queries 32 qt + 8 g + 4 lh + (0..3) of this lane's key
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const half4 v = {(half_t)dp[4 * g], (half_t)dp[4 * g + 1], (half_t)dp[4 * g + 2], (half_t)dp[4 * g + 3]};
+          *(half4*)(DSw + ds_off(wave * 32 + lr, 8 * qt + 2 * g + lh)) = v;
+        }
+      }
+      // ---- tail of the half-step: every vector-memory operation of the loop lives here, in an order that never waits on
+      // something just issued (gfx950 counts loads and stores in ONE in-order counter, and around branches hipcc waits
+      // vmcnt(0)): first CONSUME what was requested half a step or a step ago, then issue the stores, then the new loads.
+      if (qt == 1 && t + 1 < nsteps) store_tile(cur ^ 1, q0 + QT);       // tile t + 1: requested at the end of step t - 1
+      float4 v = {acc[0], acc[1], acc[2], acc[3]};
+      if constexpr (HA) {       // + the earlier sweeps' sum of the same lane at the same address (requested one step ago)
+        const float4 run = qt ? nrun1 : nrun0;      // compile-time choice
+        v.x = first ? v.x : v.x + run.x; v.y = first ? v.y : v.y + run.y;
+        v.z = first ? v.z : v.z + run.z; v.w = first ? v.w : v.w + run.w;
+      }
+      if constexpr (HA) {
+        if (!last) {
+          scr[(long long)((t - 1) * 16 + qt) * 64] = v;
+        } else {
+          const int qb = q0 - QT + 32 * qh + 16 * qt + 4 * lg;
+          half_t* o = (half_t*)p.dQ + ((long long)b * p.Lq + qb) * p.lddq + h * D + 16 * dq + l15;
+          if (qb + 0 < p.Lq) o[0] = (half_t)v.x;
+          if (qb + 1 < p.Lq) o[(long long)p.lddq] = (half_t)v.y;
+          if (qb + 2 < p.Lq) o[2LL * p.lddq] = (half_t)v.z;
+          if (qb + 3 < p.Lq) o[3LL * p.lddq] = (half_t)v.w;
+        }
+      }
+      if constexpr (HB) {       // used by the next iteration's half qt (a register pair per half: no copy of a value in flight)
+        if (!first) {
+          if (qt == 0) nrun0 = scr[(long long)(t * 16 + 0) * 64];
+          else nrun1 = scr[(long long)(t * 16 + 1) * 64];
+        }
+      }
+      if (qt == 1 && t + 2 < nsteps) load_tile(q0 + 2 * QT);
+    };
+    half(I0_{});
+    __builtin_amdgcn_sched_barrier(0);
+    half(I1_{});
+  };
+  __syncthreads();              // the previous sweep's last reads of the tile / image buffers are done
+  load_tile(0);
+  store_tile(0, 0);
+  if (nsteps > 1) load_tile(QT);
+  step(F_{}, T_{}, 0);
+  for (int t = 1; t < nsteps; ++t) step(T_{}, T_{}, t);
+  step(T_{}, F_{}, nsteps);
+
+  if (keyok) {
+    half_t* dK = (half_t*)p.dK + ((long long)b * p.Lk + key) * p.lddk + h * D;
+    half_t* dV = (half_t*)p.dV + ((long long)b * p.Lk + key) * p.lddv + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 ok_, ov_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ok_[e] = (half_t)dkt[dt][4 * g + e]; ov_[e] = (half_t)dvt[dt][4 * g + e]; }
+        *(half4*)(dK + dt * 32 + 8 * g + 4 * lh) = ok_;
+        *(half4*)(dV + dt * 32 + 8 * g + 4 * lh) = ov_;
+      }
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void attn_bwd1_kernel(const ns_attn_desc p, float* __restrict__ scratch) {
+  // LDS: two Q / dO tile pairs, two dS images, two sets of row constants.  Everything is double-buffered so that a step needs
+  // ONE barrier: step t computes its scores from tile buffer t & 1 into dS image t & 1 while the same waves form the dQ
+  // product of step t - 1 from image (t - 1) & 1 -- two independent instruction streams in one basic block (the small
+  // dQ MFMAs and their transposed reads fill the exponentials' issue slots), and the tile of step t + 1 is stored meanwhile.
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * KB * 128 + 1024];
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  const int nsteps = (p.Lq + QT - 1) / QT;
+  float4* const scr = (float4*)scratch + ((long long)bh * nsteps * 8 + (threadIdx.x >> 6)) * 2 * 64 + (threadIdx.x & 63);   // + (step * 16 + mt) * 64
+  for (int kb0 = 0; kb0 < p.Lk; kb0 += KB) {
+    const bool first = kb0 == 0, last = kb0 + KB >= p.Lk;
+    sweep(p, smem, scr, kb0, b, h, nsteps, first, last);
+  }
+}
+
+}  // namespace
+
+// scratch floats: B * H * ceil(Lq / 64) * 64 * 64
+extern "C" size_t ns_attn_bwd_workspace_bytes(int B, int H, int Lq, int Lk, int causal) {
+  if (causal || Lq < 256 || Lk < 256) return 0;      // the two-pass kernels serve these (decoder self- / cross-attention)
+  return (size_t)B * H * ((Lq + QT - 1) / QT) * QT * D * sizeof(float);
+}
+
+int ns_attn_bwd1_launch(const ns_attn_desc* d, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const size_t need = ns_attn_bwd_workspace_bytes(d->B, d->H, d->Lq, d->Lk, d->causal);
+  NS_CHECK_ARG(need > 0 && workspace && workspace_bytes >= need, "ns_attn_bwd (one pass): workspace of %zu bytes needed, %zu given",
+               need, workspace_bytes);
+  const long long items = (long long)d->B * d->Lq * d->H * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, *d);
+  hipLaunchKernelGGL(attn_bwd1_kernel, dim3(d->B * d->H), dim3(NT), 0, st, *d, (float*)workspace);
+  NS_CHECK_LAUNCH("ns_attn_bwd (one pass)");
+  return NS_OK;
+}

@@ -499,6 +499,9 @@ class MegWhisperEngine:
             b["dpre_f"] = h16(M, f)
             b["dao"] = h16(M, d)
             b["delta"] = f32(B, H, S)
+            # fp32 scratch of the one-pass attention backward (dQ summed over a head's key sweeps; ns_attn_bwd1.hip)
+            nws = ops.attn_bwd_workspace_bytes(B, H, S, S) if os.environ.get("NS_ATTN_TWO_PASS") != "1" else 0
+            b["attn_ws"] = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
             b["denc32"] = f32(M, d)
             b["dkv_c"] = h16(M, 2 * d)
             if r:
@@ -925,7 +928,7 @@ class MegWhisperEngine:
             qkv, dqkv = b["qkv"][i], b["dqkv"]
             ops.attn_bwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][i], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
                          ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][i], dO=b["dao"], dQ=dqkv, dK=(dqkv, d),
-                         dV=(dqkv, 2 * d), Delta=b["delta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
+                         dV=(dqkv, 2 * d), Delta=b["delta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d, workspace=b["attn_ws"])
             if r:
                 self._lora_du_db(dqkv, 3 * d, d, M, b["uqkv"][i], b["du3"], [lo["sBqT"], lo["sBkT"], lo["sBvT"]],
                                  [p + f"self_attn.{nm}" for nm in ("q_proj", "k_proj", "v_proj")], [sc * qs, sc, sc],

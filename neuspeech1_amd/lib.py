@@ -85,6 +85,7 @@ class AttnDesc(C.Structure):
         ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
         ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
         ("causal", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -195,6 +196,7 @@ SIGNATURES = {
     "ns_lora_bwd_dudb": (C.c_int, [C.POINTER(LoraBwdDesc), _vp]),
     "ns_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "ns_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "ns_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ns_cross_entropy": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ns_argmax_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "ns_attn_decode": (C.c_int, [C.POINTER(AttnDecodeDesc), _vp]),

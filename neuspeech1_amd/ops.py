@@ -130,8 +130,10 @@ def colsum(a16, out32, rows, cols, ld, alpha=1.0):
 
 
 def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, dO=None, dQ=None, dK=None, dV=None,
-               Delta=None, lddo=0, lddq=0, lddk=0, lddv=0):
+               Delta=None, lddo=0, lddq=0, lddk=0, lddv=0, workspace=None):
     d = AttnDesc()
+    if workspace is not None:       # one-pass backward (ns_attn_bwd_workspace_bytes > 0 for this shape)
+        d.workspace, d.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     d.Q, d.K, d.V, d.O = ptr(Q), ptr(K), ptr(V), ptr(O)
     d.dO, d.dQ, d.dK, d.dV = ptr(dO), ptr(dQ), ptr(dK), ptr(dV)
     d.LSE, d.Delta = ptr(LSE), ptr(Delta)
@@ -145,6 +147,10 @@ def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, d
 def attn_fwd(**kw):
     d = _attn_desc(**kw)
     L.check(L.load().ns_attn_fwd(C.byref(d), _stream()), "ns_attn_fwd")
+
+
+def attn_bwd_workspace_bytes(B, H, Lq, Lk, causal=False) -> int:
+    return int(L.load().ns_attn_bwd_workspace_bytes(B, H, Lq, Lk, int(causal)))
 
 
 def attn_bwd(**kw):

