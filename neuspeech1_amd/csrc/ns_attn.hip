@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     qf[s] = *(const half8*)(Q + (long long)qrow * p.ldq + 16 * s + 8 * lh);
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
     // log2(e) rides on the query fragment (used for S only; dQ = dS K reads K): S' = S log2(e) comes out of the MFMA and the
     // probability is exp2(S' - lse log2(e)) with no multiply per score (32 of the ~190 VALU issue slots per tile and lane)
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
       for (int r = 0; r < 16; ++r) { st[kt][r] = -lse * LOG2E; dp[kt][r] = -delta; }
 #else
       for (int r = 0; r < 16; ++r) { st[kt][r] = -lse; dp[kt][r] = -delta; }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const ns_attn_desc 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
       for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r]) * dp[kt][r];   // dS^T
 #else
       for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] * LOG2E) * dp[kt][r];   // dS^T
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
   for (int s = 0; s < 4; ++s) {
     kf[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
     vf[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
     // log2(e) rides on the key fragment (used for S only; dK = dS^T Q reads Q from LDS), see attn_bwd_dq_kernel
 #pragma unroll
     for (int j = 0; j < 8; ++j) kf[s][j] = (half_t)((float)kf[s][j] * LOG2E);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
     // -lse / -delta of the tile's 64 queries; queries past Lq get -inf so their probabilities vanish without a mask
     if (threadIdx.x < 64) {
       const bool qok = q0 + (int)threadIdx.x < p.Lq;
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
       lse_s[threadIdx.x] = qok ? -lse_r * LOG2E : -INFINITY;
 #else
       lse_s[threadIdx.x] = qok ? -lse_r : -INFINITY;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-#ifndef NS_ATTN_NO_LOG2
+#ifdef NS_ATTN_LOG2_ON_OPERAND
         const float pv = __builtin_amdgcn_exp2f(st[qt][r]);
 #else
         const float pv = __builtin_amdgcn_exp2f(st[qt][r] * LOG2E);
