@@ -24,11 +24,15 @@
 // consume -> store -> request (gfx950 has ONE in-order counter for loads and stores and hipcc waits vmcnt(0) around
 // branches): a request is never waited for in the half-step that issued it.
 //
-// Measured (B 64, H 8, S 1500, random data, tools/probe/attn_bwd_ab.py): 1.13-1.14 ms against 1.19-1.22 ms for the two
-// passes, and 1.6x (|S| ~ 10) to 6x (|S| ~ 40) closer to fp32 autograd, because the recomputed P is the forward's P (the
-// two-pass kernels fold log2(e) into an fp16 operand).  The waves are parked half of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES
-// = 0.49 against 0.24 for the two-pass kernels, which run two independent 4-wave workgroups per CU): eight waves in
-// lock-step behind one barrier expose every LDS round trip; issued instructions are 26 % fewer.
+// Measured (B 64, H 8, S 1500, random data, tools/probe/attn_bwd_ab.py, same box): 1.06 ms against 1.27 ms for the two
+// passes (0.83x), and 1.6x (|S| ~ 10) to 6x (|S| ~ 40) closer to fp32 autograd than the round-2 two-pass kernels, which
+// folded log2(e) into an fp16 operand.  In-kernel stamps (-DNS_AB1_STAMPS): 11 % of a wave's cycles at the step barrier,
+// 74 % in the two half-steps, 15 % in the sweeps' prologues / epilogues (K / V fragments, the K image, first tile, dK / dV
+// stores).  Waves 4-7 (the second-dispatched half, the loser of every issue arbitration against its SIMD partner) need 1.6x
+// the time of waves 0-3 for the first half-step after the barrier re-aligns the two; waves 0-3 then sit at the next barrier.
+// What cost the most on the way here, all found in the ISA rather than in the source: 64 two-byte K^T loads per lane that
+// hipcc serialised behind a vmcnt(0) each; global addresses hoisted out of the sweep loop as 64-bit pairs, spilled, and
+// reloaded one by one; a loaded value COPIED (register rotation) right after its request.
 #include "ns_common.h"
 
 namespace {
@@ -96,25 +100,48 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const ns_attn_desc p) {
 }
 
 
+// global accesses as (wave-uniform base pointer) + (32-bit byte offset of the lane): one VGPR per address instead of a 64-bit
+// pair (hipcc spilled those pairs around the sweep loop and reloaded each behind its own s_waitcnt vmcnt(0): 25 serialised
+// round trips, ~50 k cycles per sweep).  Every offset stays far below 4 GiB: they are relative to the (batch, head) base.
+template <class T>
+__device__ __forceinline__ T ns_ld(const void* base, uint32_t byte_off) { return *(const T*)((const char*)base + byte_off); }
+template <class T>
+__device__ __forceinline__ void ns_st(void* base, uint32_t byte_off, const T& v) { *(T*)((char*)base + byte_off) = v; }
+
 struct I0_ { static constexpr int value = 0; };
 struct I1_ { static constexpr int value = 1; };
 struct T_ { static constexpr bool value = true; };
 struct F_ { static constexpr bool value = false; };
 
 // One sweep (256 keys) of one (batch, head).  first: no earlier partial dQ to add; last: the sum leaves as fp16 dQ.
-__device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4* scr, int kb0, int b, int h, int nsteps,
-                                      const bool first, const bool last) {
+#ifdef NS_AB1_STAMPS
+#define NS_AB1_T() __builtin_amdgcn_s_memtime()
+#else
+#define NS_AB1_T() 0ull
+#endif
+__device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* scr, int kb0, int b, int h, int nsteps,
+                                      const bool first, const bool last, unsigned long long* tacc) {
   char* const DS0 = smem + 32768;
   float* const rc0 = (float*)(smem + 32768 + 2 * KB * 128);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  // (the thread index is laundered once per sweep: everything derived from it -- LDS and global lane offsets -- would
+  // otherwise be hoisted out of the sweep loop as loop-invariant, kept live across it and SPILLED, each reload behind
+  // its own s_waitcnt vmcnt(0); recomputing them per sweep is a handful of VALU instructions)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
   const int l15 = lane & 15, lg = lane >> 4;
-  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
-  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
-  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
-  const half_t* dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
-  const float* LSE = p.LSE + ((long long)b * p.H + h) * p.Lq;
-  const float* Delta = p.Delta + ((long long)b * p.H + h) * p.Lq;
+  // wave-uniform bases of this (batch, head)
+  const half_t* const Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* const K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* const V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const half_t* const dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
+  half_t* const dQ = (half_t*)p.dQ + (long long)b * p.Lq * p.lddq + h * D;
+  half_t* const dK = (half_t*)p.dK + (long long)b * p.Lk * p.lddk + h * D;
+  half_t* const dV = (half_t*)p.dV + (long long)b * p.Lk * p.lddv + h * D;
+  const float* const LSE = p.LSE + ((long long)b * p.H + h) * p.Lq;
+  const float* const Delta = p.Delta + ((long long)b * p.H + h) * p.Lq;
   const int qh = wave & 1, dq = wave >> 1;
+  const uint32_t scr_lane = (uint32_t)(wave * 128 + lane) * 16u;     // + (step * 16 + mt) * 1024 bytes
   const int srow = tid >> 3, sch = tid & 7;
   const int s_off = lds_off(srow, sch);
 
@@ -124,8 +151,8 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
   half8 kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    kf[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
-    vf[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
+    kf[s] = ns_ld<half8>(K, 2u * ((uint32_t)krow * p.ldk + 16 * s + 8 * lh));
+    vf[s] = ns_ld<half8>(V, 2u * ((uint32_t)krow * p.ldv + 16 * s + 8 * lh));
   }
   // K^T fragments of the dQ product (B operand of 16x16x32: lane n = d column, 8 consecutive keys per k-group): the sweep's
   // K rows go through LDS once (coalesced 16-B loads into the second dS image, which no step has touched yet) and come
@@ -133,15 +160,34 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
   // (Fetched straight from global memory these are 64 two-byte loads per lane, which hipcc serialised behind one
   // s_waitcnt vmcnt(0) each: ~0.4 ms per launch.)
   half8 ktf[8];
+  uint4 qreg, dreg;
+  float lse_r = 0.f, del_r = 0.f;
+  auto load_tile = [&](int q0) __attribute__((always_inline)) {
+    const uint32_t rr = (uint32_t)min(q0 + srow, p.Lq - 1);
+    qreg = ns_ld<uint4>(Q, 2u * (rr * p.ldq + sch * 8));
+    dreg = ns_ld<uint4>(dO, 2u * (rr * p.lddo + sch * 8));
+    if (tid < 64) { const uint32_t qq = (uint32_t)min(q0 + tid, p.Lq - 1); lse_r = ns_ld<float>(LSE, 4u * qq); del_r = ns_ld<float>(Delta, 4u * qq); }
+  };
+  int q_first = 0;
+  asm volatile("" : "+s"(q_first));
   {
     char* const KT = DS0 + KB * 128;
-    __syncthreads();            // the previous sweep's last dQ reads of this image are done
+    // every request of the sweep's prologue goes out before anything waits: the K rows for the image, then the first tile
+    uint4 kv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int piece = tid + NT * i;             // 2048 pieces of 16 B: key = piece >> 3, chunk = piece & 7
       const int kk = kb0 + (piece >> 3);
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (kk < p.Lk) v = *(const uint4*)(K + (long long)kk * p.ldk + (piece & 7) * 8);
+      kv[i] = ns_ld<uint4>(K, 2u * ((uint32_t)min(kk, p.Lk - 1) * p.ldk + (piece & 7) * 8));
+    }
+    load_tile(q_first);
+    __syncthreads();            // the previous sweep's last reads of the images and tile buffers are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = tid + NT * i;
+      const bool ok = kb0 + (piece >> 3) < p.Lk;
+      uint4 v = kv[i];
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
       *(uint4*)(KT + piece * 16) = v;
     }
     __syncthreads();
@@ -160,14 +206,6 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[t][r] = 0.f; dvt[t][r] = 0.f; }
 
-  uint4 qreg, dreg;
-  float lse_r = 0.f, del_r = 0.f;
-  auto load_tile = [&](int q0) __attribute__((always_inline)) {
-    const long long rr = min(q0 + srow, p.Lq - 1);
-    qreg = *(const uint4*)(Q + rr * p.ldq + sch * 8);
-    dreg = *(const uint4*)(dO + rr * p.lddo + sch * 8);
-    if (tid < 64) { const int qq = min(q0 + tid, p.Lq - 1); lse_r = LSE[qq]; del_r = Delta[qq]; }
-  };
   auto store_tile = [&](int buf, int q0) __attribute__((always_inline)) {
     *(uint4*)(smem + buf * 16384 + s_off) = qreg;
     *(uint4*)(smem + buf * 16384 + 8192 + s_off) = dreg;
@@ -182,7 +220,10 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
   auto step = [&](auto HA_, auto HB_, int t) __attribute__((always_inline)) {
     constexpr bool HA = decltype(HA_)::value, HB = decltype(HB_)::value;
     const int q0 = t * QT, cur = t & 1;
+    const unsigned long long t_b = NS_AB1_T();
     __syncthreads();
+    const unsigned long long t_a = NS_AB1_T();
+    tacc[0] += t_a - t_b;                 // parked at the barrier
     const char* const Qs = smem + cur * 16384;
     const char* const dOs = Qs + 8192;
     char* const DSw = DS0 + cur * (KB * 128);
@@ -263,39 +304,44 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
       }
       if constexpr (HA) {
         if (!last) {
-          scr[(long long)((t - 1) * 16 + qt) * 64] = v;
+          ns_st<float4>(scr, scr_lane + (uint32_t)((t - 1) * 16 + qt) * 1024u, v);
         } else {
           const int qb = q0 - QT + 32 * qh + 16 * qt + 4 * lg;
-          half_t* o = (half_t*)p.dQ + ((long long)b * p.Lq + qb) * p.lddq + h * D + 16 * dq + l15;
-          if (qb + 0 < p.Lq) o[0] = (half_t)v.x;
-          if (qb + 1 < p.Lq) o[(long long)p.lddq] = (half_t)v.y;
-          if (qb + 2 < p.Lq) o[2LL * p.lddq] = (half_t)v.z;
-          if (qb + 3 < p.Lq) o[3LL * p.lddq] = (half_t)v.w;
+          const uint32_t o = 2u * ((uint32_t)qb * p.lddq + 16 * dq + l15), ro = 2u * (uint32_t)p.lddq;
+          if (qb + 0 < p.Lq) ns_st<half_t>(dQ, o, (half_t)v.x);
+          if (qb + 1 < p.Lq) ns_st<half_t>(dQ, o + ro, (half_t)v.y);
+          if (qb + 2 < p.Lq) ns_st<half_t>(dQ, o + 2 * ro, (half_t)v.z);
+          if (qb + 3 < p.Lq) ns_st<half_t>(dQ, o + 3 * ro, (half_t)v.w);
         }
       }
       if constexpr (HB) {       // used by the next iteration's half qt (a register pair per half: no copy of a value in flight)
         if (!first) {
-          if (qt == 0) nrun0 = scr[(long long)(t * 16 + 0) * 64];
-          else nrun1 = scr[(long long)(t * 16 + 1) * 64];
+          if (qt == 0) nrun0 = ns_ld<float4>(scr, scr_lane + (uint32_t)(t * 16 + 0) * 1024u);
+          else nrun1 = ns_ld<float4>(scr, scr_lane + (uint32_t)(t * 16 + 1) * 1024u);
         }
       }
       if (qt == 1 && t + 2 < nsteps) load_tile(q0 + 2 * QT);
     };
     half(I0_{});
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t_m = NS_AB1_T();
     half(I1_{});
+    const unsigned long long t_e = NS_AB1_T();
+    tacc[1] += t_m - t_a;                 // first half
+    tacc[2] += t_e - t_m;                 // second half
   };
-  __syncthreads();              // the previous sweep's last reads of the tile / image buffers are done
-  load_tile(0);
-  store_tile(0, 0);
-  if (nsteps > 1) load_tile(QT);
-  step(F_{}, T_{}, 0);
+  store_tile(0, q_first);
+  if (nsteps > 1) load_tile(q_first + QT);
+  // (the step index of the two peeled iterations is laundered through an SGPR: as compile-time constants their global
+  // addresses are loop-invariant 64-bit pairs that hipcc hoists out of the sweep loop, spills, and reloads one by one)
+  int t_first = 0, t_last = nsteps;
+  asm volatile("" : "+s"(t_first));
+  asm volatile("" : "+s"(t_last));
+  step(F_{}, T_{}, t_first);
   for (int t = 1; t < nsteps; ++t) step(T_{}, T_{}, t);
-  step(T_{}, F_{}, nsteps);
+  step(T_{}, F_{}, t_last);
 
   if (keyok) {
-    half_t* dK = (half_t*)p.dK + ((long long)b * p.Lk + key) * p.lddk + h * D;
-    half_t* dV = (half_t*)p.dV + ((long long)b * p.Lk + key) * p.lddv + h * D;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -303,10 +349,14 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float4*
         half4 ok_, ov_;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ok_[e] = (half_t)dkt[dt][4 * g + e]; ov_[e] = (half_t)dvt[dt][4 * g + e]; }
-        *(half4*)(dK + dt * 32 + 8 * g + 4 * lh) = ok_;
-        *(half4*)(dV + dt * 32 + 8 * g + 4 * lh) = ov_;
+        ns_st<half4>(dK, 2u * ((uint32_t)key * p.lddk + dt * 32 + 8 * g + 4 * lh), ok_);
+        ns_st<half4>(dV, 2u * ((uint32_t)key * p.lddv + dt * 32 + 8 * g + 4 * lh), ov_);
       }
   }
+}
+
+__device__ __forceinline__ size_t ns_attn_bwd_workspace_bytes_dev(const ns_attn_desc& p) {
+  return (size_t)p.B * p.H * ((p.Lq + QT - 1) / QT) * QT * D * sizeof(float);
 }
 
 __global__ __launch_bounds__(NT, 2) void attn_bwd1_kernel(const ns_attn_desc p, float* __restrict__ scratch) {
@@ -317,11 +367,20 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd1_kernel(const ns_attn_desc p, 
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * KB * 128 + 1024];
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nsteps = (p.Lq + QT - 1) / QT;
-  float4* const scr = (float4*)scratch + ((long long)bh * nsteps * 8 + (threadIdx.x >> 6)) * 2 * 64 + (threadIdx.x & 63);   // + (step * 16 + mt) * 64
+  float* const scr = scratch + (long long)bh * nsteps * (QT * D);   // this (batch, head)'s part: [step][wave][mt][lane] float4
+  unsigned long long tacc[3] = {0ull, 0ull, 0ull};
+  const unsigned long long t_start = NS_AB1_T();
+  (void)t_start;
   for (int kb0 = 0; kb0 < p.Lk; kb0 += KB) {
     const bool first = kb0 == 0, last = kb0 + KB >= p.Lk;
-    sweep(p, smem, scr, kb0, b, h, nsteps, first, last);
+    sweep(p, smem, scr, kb0, b, h, nsteps, first, last, tacc);
   }
+#ifdef NS_AB1_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* out = (unsigned long long*)((char*)scratch + ns_attn_bwd_workspace_bytes_dev(p)) + ((long long)bh * 8 + (threadIdx.x >> 6)) * 4;
+    out[0] = tacc[0]; out[1] = tacc[1]; out[2] = tacc[2]; out[3] = NS_AB1_T() - t_start;
+  }
+#endif
 }
 
 }  // namespace

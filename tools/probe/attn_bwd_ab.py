@@ -21,7 +21,8 @@ ops.attn_fwd(**common)
 dO = (torch.randn(B * S, d, device=dev, generator=g) * 0.5).half()
 dqkv = torch.zeros(B * S, 3 * d, device=dev, dtype=torch.float16)
 Delta = torch.zeros(B, H, S, device=dev)
-ws = torch.empty(ops.attn_bwd_workspace_bytes(B, H, S, S), device=dev, dtype=torch.uint8)
+NEED = ops.attn_bwd_workspace_bytes(B, H, S, S)
+ws = torch.zeros(NEED + B * H * 8 * 32, device=dev, dtype=torch.uint8)   # + room for the diagnostic build's stamps
 bw = dict(dO=dO, dQ=dqkv, dK=(dqkv, d), dV=(dqkv, 2 * d), Delta=Delta, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
 
 
@@ -47,3 +48,12 @@ for k, v in res.items():
     ms = min(v)
     n = 1 if k == "fwd" else 2.5
     print(f"{k}: min {ms:.3f} ms  median {sorted(v)[len(v) // 2]:.3f} ms  -> {n * fl / ms / 1e9:.0f} TFLOP/s algorithmic")
+
+if os.environ.get("NS_EXTRA_HIPCC_FLAGS", "").find("NS_AB1_STAMPS") >= 0:
+    torch.cuda.synchronize()
+    st = ws[NEED:].view(torch.int64).view(B * H, 8, 4).double()
+    tot = st[:, :, 3].mean().item()
+    print(f"stamps (cycles per workgroup-wave, mean): total {tot:.0f}; barrier {st[:, :, 0].mean().item():.0f} ({100 * st[:, :, 0].mean().item() / tot:.1f} %), "
+          f"first half {st[:, :, 1].mean().item():.0f}, second half {st[:, :, 2].mean().item():.0f}")
+    print("per wave barrier share:", [round(st[:, w, 0].mean().item() / tot, 3) for w in range(8)])
+    print("per wave half1:", [round(st[:, w, 1].mean().item() / tot, 3) for w in range(8)], "half2:", [round(st[:, w, 2].mean().item() / tot, 3) for w in range(8)])
