@@ -27,7 +27,7 @@ GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
 # fwd+bwd" is measured on
 ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
-PMC_FILE = "profiles/r2_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
+PMC_FILE = "profiles/r3_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 
 
 def cpu_baseline(dims, r, alpha):

@@ -303,7 +303,11 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
         v.z = first ? v.z : v.z + run.z; v.w = first ? v.w : v.w + run.w;
       }
       if constexpr (HA) {
+#ifdef NS_AB1_NOSCR   /* diagnostic: no scratch traffic (wrong dQ) */
+        if (false) {
+#else
         if (!last) {
+#endif
           ns_st<float4>(scr, scr_lane + (uint32_t)((t - 1) * 16 + qt) * 1024u, v);
         } else {
           const int qb = q0 - QT + 32 * qh + 16 * qt + 4 * lg;
@@ -315,7 +319,11 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
         }
       }
       if constexpr (HB) {       // used by the next iteration's half qt (a register pair per half: no copy of a value in flight)
+#ifdef NS_AB1_NOSCR
+        if (false) {
+#else
         if (!first) {
+#endif
           if (qt == 0) nrun0 = ns_ld<float4>(scr, scr_lane + (uint32_t)(t * 16 + 0) * 1024u);
           else nrun1 = ns_ld<float4>(scr, scr_lane + (uint32_t)(t * 16 + 1) * 1024u);
         }

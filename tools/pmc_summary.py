@@ -1,5 +1,5 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE rocprofv3 passes of tools/profile.sh pmc <tag> into
-gpurun_out/pmc_<tag>_traffic.json (copy it to profiles/r2_pmc_traffic.json): HBM bytes per launch of every kernel,
+gpurun_out/pmc_<tag>_traffic.json (copy it to profiles/r3_pmc_traffic.json): HBM bytes per launch of every kernel,
 FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md §HBM), WRITE_SIZE as is; both counters
 are in KB.  The record carries the sha256 of the dominant kernel's source so that bench.py can refuse a stale file."""
 import csv

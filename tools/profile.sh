@@ -11,18 +11,20 @@ OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 mode="$1"; tag="$2"; shift 2
 cd /tmp && export TMPDIR=/tmp
+# counter passes run the step EAGERLY (NS_TRAIN_GRAPH=0: same kernels, one dispatch record per launch); the stats pass keeps the
+# default (hipGraph replay), which is what bench.py times
 case "$mode" in
   stats)
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_$tag.json" 2> "$OUT/prof_$tag.log"
     ;;
   pmc)
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_$c.json" 2> "$OUT/pmc_${tag}_$c.log"
+      NS_TRAIN_GRAPH=0 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_$c.json" 2> "$OUT/pmc_${tag}_$c.log"
     done
     python3 "$ROOT/tools/pmc_summary.py" "$tag"
     ;;
   sq)
-    rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_${tag}_SQ" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_SQ.json" 2> "$OUT/pmc_${tag}_SQ.log"
+    NS_TRAIN_GRAPH=0 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_${tag}_SQ" -o p -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-eval > "$OUT/pmc_${tag}_SQ.json" 2> "$OUT/pmc_${tag}_SQ.log"
     python3 "$ROOT/tools/pmc_sq_summary.py" "$tag"
     ;;
   decode)
