@@ -11,19 +11,22 @@ from neuspeech1_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, H, S = int(os.environ.get("B", 64)), 8, 1500
+LQ = int(os.environ.get("LQ", S))     # LQ=45: the decoder's cross-attention shape
 d = H * 64
 g = torch.Generator(device=dev).manual_seed(1)
 qkv = (torch.randn(B * S, 3 * d, device=dev, generator=g) * 0.5).half()
-O = torch.zeros(B * S, d, device=dev, dtype=torch.float16)
-LSE = torch.zeros(B, H, S, device=dev)
-common = dict(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=O, B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, causal=False, LSE=LSE)
+qx = (torch.randn(B * LQ, d, device=dev, generator=g) * 0.5).half()
+O = torch.zeros(B * LQ, d, device=dev, dtype=torch.float16)
+LSE = torch.zeros(B, H, LQ, device=dev)
+common = dict(Q=qx if LQ != S else qkv, K=(qkv, d), V=(qkv, 2 * d), O=O, B=B, H=H, Lq=LQ, Lk=S, ldq=d if LQ != S else 3 * d, ldk=3 * d, ldv=3 * d, ldo=d, causal=False, LSE=LSE)
 ops.attn_fwd(**common)
-dO = (torch.randn(B * S, d, device=dev, generator=g) * 0.5).half()
+dO = (torch.randn(B * LQ, d, device=dev, generator=g) * 0.5).half()
+dqx = torch.zeros(B * LQ, d, device=dev, dtype=torch.float16)
 dqkv = torch.zeros(B * S, 3 * d, device=dev, dtype=torch.float16)
-Delta = torch.zeros(B, H, S, device=dev)
-NEED = ops.attn_bwd_workspace_bytes(B, H, S, S)
+Delta = torch.zeros(B, H, LQ, device=dev)
+NEED = ops.attn_bwd_workspace_bytes(B, H, LQ, S)
 ws = torch.zeros(NEED + B * H * 8 * 32, device=dev, dtype=torch.uint8)   # + room for the diagnostic build's stamps
-bw = dict(dO=dO, dQ=dqkv, dK=(dqkv, d), dV=(dqkv, 2 * d), Delta=Delta, lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
+bw = dict(dO=dO, dQ=dqx if LQ != S else dqkv, dK=(dqkv, d), dV=(dqkv, 2 * d), Delta=Delta, lddo=d, lddq=d if LQ != S else 3 * d, lddk=3 * d, lddv=3 * d)
 
 
 def t(fn, n=10):
@@ -43,7 +46,7 @@ for _ in range(4):
     res["fwd"].append(t(lambda: ops.attn_fwd(**common)))
     res["two"].append(t(lambda: ops.attn_bwd(**common, **bw)))
     res["one"].append(t(lambda: ops.attn_bwd(**common, **bw, workspace=ws)))
-fl = 4.0 * B * H * S * S * 64
+fl = 4.0 * B * H * LQ * S * 64
 for k, v in res.items():
     ms = min(v)
     n = 1 if k == "fwd" else 2.5
