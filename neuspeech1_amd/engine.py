@@ -187,7 +187,8 @@ class MegWhisperEngine:
         self._bufs = {}
         # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
         self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
-        self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 24, 0
+        self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 48, 0
+        self.label_pad = 16
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
         self._init_opt_state()
@@ -1084,6 +1085,13 @@ class MegWhisperEngine:
         them.  The first step of a shape runs eagerly (lazy allocations), the second is captured."""
         if not self._graph_usable(x32):
             return self._train_step_eager(x32, labels, on_ready, reduce_fn)
+        # label lengths vary from batch to batch (the longest transcript of the batch): pad them to a multiple of 16 with the
+        # ignore index so that a recipe needs a handful of graphs, not one per length.  Exactly neutral: padded positions are
+        # ignored by the loss, lie behind every real position under the causal mask, and the loss is a mean over valid tokens.
+        L = labels.shape[1]
+        Lp = (L + self.label_pad - 1) // self.label_pad * self.label_pad
+        if Lp != L:
+            labels = torch.nn.functional.pad(labels, (0, Lp - L), value=-100)
         packed = isinstance(x32, PackedSignal)
         xkey = x32.xin.data_ptr() if packed else x32.data_ptr()
         key = (tuple(x32.shape), tuple(labels.shape), xkey, on_ready is not None)
