@@ -210,9 +210,12 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
     *(uint4*)(smem + buf * 16384 + s_off) = qreg;
     *(uint4*)(smem + buf * 16384 + 8192 + s_off) = dreg;
     if (tid < 64) {
-      const bool qok = q0 + tid < p.Lq;
-      rc0[buf * 128 + tid] = qok ? -lse_r : -INFINITY;      // queries past Lq: P = exp2(-inf) = 0, so dS = 0 too
-      rc0[buf * 128 + 64 + tid] = -del_r;
+      // (wave 0: the lane id is recomputed with v_mbcnt here -- derived from the long-lived thread index the address was
+      // spilled, and its reload sat behind an s_waitcnt vmcnt(0) once per step)
+      const int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const bool qok = q0 + l < p.Lq;
+      rc0[buf * 128 + l] = qok ? -lse_r : -INFINITY;        // queries past Lq: P = exp2(-inf) = 0, so dS = 0 too
+      rc0[buf * 128 + 64 + l] = -del_r;
     }
   };
   float4 nrun0 = {0.f, 0.f, 0.f, 0.f}, nrun1 = {0.f, 0.f, 0.f, 0.f};    // running dQ sums in flight (see the step's tail)

@@ -1,0 +1,109 @@
+"""Build-time ISA checks (no GPU): properties of the hand-written kernels that the C++ source cannot express and that
+depend on hipcc's register allocation, checked on the gfx950 assembly of the sources as they are.
+
+* `ns_gemm_p8_kernel` loads the LoRA fragments with inline-asm `global_load_dwordx4` whose results are only valid after a
+  LATER inline-asm `s_waitcnt` (the compiler believes the value exists right behind the load statement): between a load
+  and the wait that covers it no instruction may read, copy or spill the destination registers.
+* the hot kernels must not touch scratch memory (a spill inside the hand-counted vmcnt sequences would also break them).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neuspeech1_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (cross-compiles gfx950 without a GPU)")
+
+
+def _asm(src, tmp_path):
+    out = str(tmp_path / (src + ".s"))
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-ffp-contract=fast", "-S",
+                    "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, capture_output=True)
+    return open(out).read()
+
+
+def _kernels(asm):
+    """name -> list of instruction lines of every kernel body in the assembly"""
+    out, cur = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+        elif cur is not None:
+            if line.startswith("\t.section") or line.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                out[cur].append(line)
+    return out
+
+
+def _regs(tok):
+    """register numbers named by an operand token like v12 or v[12:15]"""
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path):
+    kernels = {k: v for k, v in _kernels(_asm("ns_gemm_p8.hip", tmp_path)).items() if "ns_gemm_p8_kernel" in k}
+    assert len(kernels) == 2, list(kernels)
+    for name, body in kernels.items():
+        pending, in_asm, checked = set(), False, 0
+        for line in body:
+            s = line.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if s.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not s or s.startswith(";") or s.startswith("."):
+                continue
+            ops = [t.strip() for t in re.split(r"[ ,]+", s.split(";")[0].strip()) if t.strip()]
+            if in_asm and ops[0] == "global_load_dwordx4":
+                pending |= _regs(ops[1])
+                continue
+            if in_asm and ops[0] == "s_waitcnt" and pending:
+                pending.clear()            # vmcnt(12) / vmcnt(0) behind the fragment loads: they have landed
+                checked += 1
+                continue
+            if pending:
+                # any instruction between the loads and their wait: none of its operands may be a pending register
+                touched = set().union(*[_regs(t) for t in ops[1:]]) if len(ops) > 1 else set()
+                assert not (touched & pending), f"{name}: `{s}` touches {sorted(touched & pending)} before the covering s_waitcnt"
+        assert checked >= 1, f"{name}: no fragment-load / wait pair found (did the kernel change?)"
+        assert not pending
+
+
+@pytest.mark.parametrize("src,kernel", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel"), ("ns_gemm_tn256.hip", "ns_gemm_tn256_kernel"),
+                                        ("ns_lora_bwd.hip", "lora_bwd_dudb_kernel"), ("ns_attn.hip", "attn_fwd_kernel")])
+def test_hot_kernels_use_no_scratch(tmp_path, src, kernel):
+    ks = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
+    assert ks, src
+    for name, body in ks.items():
+        bad = [l.strip() for l in body if re.match(r"\s*scratch_(load|store)", l)]
+        assert not bad, f"{name}: {len(bad)} scratch accesses, e.g. {bad[:2]}"
+
+
+def test_one_pass_attention_backward_steady_state_has_no_scratch_and_one_vmem_wait(tmp_path):
+    """attn_bwd1_kernel: the 8 spilled registers live in the sweep prologue; the step loop (the deepest loop that holds the MFMAs)
+    must be clean, and it must wait for vector memory exactly once per step (the tail discipline of ns_attn_bwd1.hip)."""
+    body = [v for k, v in _kernels(_asm("ns_attn_bwd1.hip", tmp_path)).items() if "attn_bwd1_kernel" in k][0]
+    text = "\n".join(body)
+    # the steady-state step = the innermost loop: from its header comment to the backward branch
+    m = list(re.finditer(r"Inner Loop Header: Depth=2", text))
+    assert m, "no depth-2 inner loop found"
+    loop = text[m[0].start():]
+    end = re.search(r"s_cbranch_\w+ \.LBB\d+_\d+\n[^\n]*\n\.LBB", loop)
+    loop = loop[:end.start()] if end else loop[:60000]
+    n_mfma = len(re.findall(r"v_mfma_", loop))
+    assert n_mfma >= 48, n_mfma                      # 2 halves x (8 + 8 big + 8 small)
+    assert not re.search(r"scratch_(load|store)", loop)
+    assert len(re.findall(r"s_waitcnt vmcnt", loop)) <= 2
