@@ -474,10 +474,11 @@ extern "C" int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_
   NS_CHECK_ARG(workspace && workspace_bytes >= ns_orth_reg_workspace_bytes(njobs),
                "ns_orth_reg: workspace of %zu bytes is smaller than ns_orth_reg_workspace_bytes(%d)", workspace_bytes, njobs);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, ns_orth_reg_workspace_bytes(njobs), st) != hipSuccess) {
-    ns_set_error("ns_orth_reg: hipMemsetAsync failed");
-    return NS_ERR_HIP;
-  }
+  // cleared by a KERNEL, not by hipMemsetAsync: captured in a hipGraph (engine.train_step) the memset node was not reliably
+  // ordered against the kernel nodes around it under back-to-back replays -- the AdaLoRA step reported a garbage / inf
+  // regulariser value every few dozen replays (tools/soak_train.py ... adalora), never with eager launches
+  const size_t nwords = ns_orth_reg_workspace_bytes(njobs) / 4;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((nwords + 1023) / 1024)), dim3(256), 0, st, (uint32_t*)workspace, 0u, nwords);
   hipLaunchKernelGGL(orth_gram_kernel, dim3(njobs, ORTH_SPLIT), dim3(256), 0, st, jobs_dev, (float*)workspace);
   hipLaunchKernelGGL(orth_grad_kernel, dim3(njobs, ORTH_SPLIT), dim3(256), 0, st, jobs_dev, (const float*)workspace, weight_over_num,
                      loss_scale_dev, reg_out_dev);

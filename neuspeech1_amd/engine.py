@@ -188,7 +188,7 @@ class MegWhisperEngine:
         # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
         self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 48, 0
-        self.label_pad = 16
+        self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
         self._init_opt_state()
