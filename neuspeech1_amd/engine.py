@@ -1094,7 +1094,11 @@ class MegWhisperEngine:
             labels = torch.nn.functional.pad(labels, (0, Lp - L), value=-100)
         packed = isinstance(x32, PackedSignal)
         xkey = x32.xin.data_ptr() if packed else x32.data_ptr()
-        key = (tuple(x32.shape), tuple(labels.shape), xkey, on_ready is not None)
+        # everything a captured launch argument was computed from: shapes, the input buffer, the exchange cuts, and the
+        # host-side settings that ride in kernel arguments (optimizer hyper-parameters, dropout rate, the seed base)
+        import dataclasses
+        key = (tuple(x32.shape), tuple(labels.shape), xkey, on_ready is not None, dataclasses.astuple(self.tc),
+               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs)
         g = self._graphs.get(key)
         if g is None:
             warm = (tuple(x32.shape), tuple(labels.shape))
