@@ -74,7 +74,8 @@ __device__ __forceinline__ half8 cvt8(const f32x16& x, int base) {
 __device__ __forceinline__ int ds_swz(int k) { return ((k >> 1) & 1) << 2 | ((k >> 3) & 1) << 3 | (k & 1) | ((k >> 2) & 1) << 1; }
 __device__ __forceinline__ int ds_off(int k, int qg) { return 128 * k + 8 * (qg ^ ds_swz(k)); }
 
-// delta[b][h][q] = sum_d dO[q][d] O[q][d]   (8 lanes per (row, head))
+// delta[b][h][q] = sum_d dO[q][d] O[q][d]   (8 lanes per (row, head)).  Only launched with -DNS_AB1_DELTA_KERNEL: the first sweep of
+// attn_bwd1_kernel forms delta itself from the dO chunks its staging threads hold (same arithmetic, same order: bitwise equal).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const ns_attn_desc p) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long item = t >> 3;                 // (row, head)
@@ -160,13 +161,19 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   // (Fetched straight from global memory these are 64 two-byte loads per lane, which hipcc serialised behind one
   // s_waitcnt vmcnt(0) each: ~0.4 ms per launch.)
   half8 ktf[8];
-  uint4 qreg, dreg;
+  const half_t* const Oin = (const half_t*)p.O + (long long)b * p.Lq * p.ldo + h * D;
+  uint4 qreg, dreg, oreg = {0u, 0u, 0u, 0u};
   float lse_r = 0.f, del_r = 0.f;
   auto load_tile = [&](int q0) __attribute__((always_inline)) {
     const uint32_t rr = (uint32_t)min(q0 + srow, p.Lq - 1);
     qreg = ns_ld<uint4>(Q, 2u * (rr * p.ldq + sch * 8));
     dreg = ns_ld<uint4>(dO, 2u * (rr * p.lddo + sch * 8));
-    if (tid < 64) { const uint32_t qq = (uint32_t)min(q0 + tid, p.Lq - 1); lse_r = ns_ld<float>(LSE, 4u * qq); del_r = ns_ld<float>(Delta, 4u * qq); }
+    if (first) oreg = ns_ld<uint4>(Oin, 2u * (rr * p.ldo + sch * 8));      // first sweep: delta is formed here (see store_tile)
+    if (tid < 64) {
+      const uint32_t qq = (uint32_t)min(q0 + tid, p.Lq - 1);
+      lse_r = ns_ld<float>(LSE, 4u * qq);
+      if (!first) del_r = ns_ld<float>(Delta, 4u * qq);
+    }
   };
   int q_first = 0;
   asm volatile("" : "+s"(q_first));
@@ -209,13 +216,28 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   auto store_tile = [&](int buf, int q0) __attribute__((always_inline)) {
     *(uint4*)(smem + buf * 16384 + s_off) = qreg;
     *(uint4*)(smem + buf * 16384 + 8192 + s_off) = dreg;
+    if (first) {
+      // delta[q] = sum_d dO[q][d] O[q][d] of the tile's rows, from the chunks the staging threads hold anyway (eight lanes per
+      // row): the separate delta launch (33 us, 196 MB) is gone.  The first sweep stores it for the later ones.
+      const half8 a = __builtin_bit_cast(half8, dreg), o = __builtin_bit_cast(half8, oreg);
+      float sdot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sdot += (float)a[j] * (float)o[j];
+      sdot += __shfl_xor(sdot, 1, 64);
+      sdot += __shfl_xor(sdot, 2, 64);
+      sdot += __shfl_xor(sdot, 4, 64);
+      if (sch == 0) {
+        rc0[buf * 128 + 64 + srow] = -sdot;
+        if (q0 + srow < p.Lq) ns_st<float>(p.Delta + ((long long)b * p.H + h) * p.Lq, 4u * (uint32_t)(q0 + srow), sdot);
+      }
+    }
     if (tid < 64) {
       // (wave 0: the lane id is recomputed with v_mbcnt here -- derived from the long-lived thread index the address was
       // spilled, and its reload sat behind an s_waitcnt vmcnt(0) once per step)
       const int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       const bool qok = q0 + l < p.Lq;
       rc0[buf * 128 + l] = qok ? -lse_r : -INFINITY;        // queries past Lq: P = exp2(-inf) = 0, so dS = 0 too
-      rc0[buf * 128 + 64 + l] = -del_r;
+      if (!first) rc0[buf * 128 + 64 + l] = -del_r;
     }
   };
   float4 nrun0 = {0.f, 0.f, 0.f, 0.f}, nrun1 = {0.f, 0.f, 0.f, 0.f};    // running dQ sums in flight (see the step's tail)
@@ -410,7 +432,11 @@ int ns_attn_bwd1_launch(const ns_attn_desc* d, void* workspace, size_t workspace
   NS_CHECK_ARG(need > 0 && workspace && workspace_bytes >= need, "ns_attn_bwd (one pass): workspace of %zu bytes needed, %zu given",
                need, workspace_bytes);
   const long long items = (long long)d->B * d->Lq * d->H * 8;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, *d);
+#ifdef NS_AB1_DELTA_KERNEL
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, *d);   // (the kernel's first sweep forms delta itself)
+#else
+  (void)items;
+#endif
   hipLaunchKernelGGL(attn_bwd1_kernel, dim3(d->B * d->H), dim3(NT), 0, st, *d, (float*)workspace);
   NS_CHECK_LAUNCH("ns_attn_bwd (one pass)");
   return NS_OK;
