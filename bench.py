@@ -27,6 +27,9 @@ GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
 # fwd+bwd" is measured on
 ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
+# the dominant kernel: the persistent phase-interleaved GEMM (its six instantiations) together with the one-tile-per-workgroup form it
+# falls back to (position-row epilogue, < 512 tiles) -- one arithmetic, one "nt256" class in the event-timed leg and in the rocprof rows
+DOMINANT = "ns_gemm_p8s_kernel"
 PMC_FILE = "profiles/r3_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 
 
@@ -57,7 +60,7 @@ def cpu_baseline(dims, r, alpha):
 def _kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
-    for f in ("ns_gemm_p8.hip", "ns_gemm_epi.h"):
+    for f in ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h"):
         h.update(open(os.path.join(ROOT, "neuspeech1_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -335,9 +338,9 @@ def main():
         dom = "nt256" if "nt256" in tot else "nt128"
         fl, sec, n = tot[dom]
         ach = fl / sec / 1e12
-        roof = {"bound": "mfma", "kernel": "ns_gemm_p8_kernel" if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
+        roof = {"bound": "mfma", "kernel": DOMINANT if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": _pmc_traffic("ns_gemm_p8_kernel" if dom == "nt256" else None), "traffic_source": PMC_FILE,
+                "traffic": _pmc_traffic(DOMINANT if dom == "nt256" else None), "traffic_source": PMC_FILE,
                 "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                 "gflop_per_launch": round(fl / n / 1e9, 2),
                 "step_share": {k: {"ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 1),

@@ -356,6 +356,8 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
+int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st);
+bool ns_gemm_p8s_ok(const ns_gemm_desc* d);
 bool ns_gemm_p8_fits(const ns_gemm_desc* d);
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
@@ -450,7 +452,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   if (d->side_B) {
     NS_CHECK_ARG(!tn && d->side_out && d->side_n == 32 && d->side_ldb % 8 == 0 && d->side_ldb >= d->N && (d->flags & NS_GEMM_GELU) &&
                      d->G16 && !d->H32 && !(d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) && d->splits <= 1 &&
-                     ns_gemm_side_supported(d->M, d->N, d->K) && g_use_ring == 1,
+                     ns_gemm_side_supported(d->M, d->N, d->K) && (g_use_ring == 1 || g_use_ring == 4 || g_use_ring == 9),
                  "ns_gemm: side product needs the large-M GELU form (ns_gemm_side_supported, G16, side_n = 32, side_out)");
     NS_CHECK_ARG(d->side_drop_p >= 0.f && d->side_drop_p <= 0.5f, "ns_gemm: side_drop_p out of range (0 .. 0.5)");
   }
@@ -487,14 +489,19 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
     // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the one-barrier 256^2 ring,
-    // 4 = force the phase-interleaved 256^2 kernel where it applies, 5 = auto without the phase-interleaved kernel
+    // 4 = force the phase-interleaved 256^2 kernel where it applies, 5 = auto without the phase-interleaved kernel,
+    // 9 = force its persistent form where it applies
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    const bool big = g_use_ring == 3 || g_use_ring == 4 ||
+    const bool big = g_use_ring == 3 || g_use_ring == 4 || g_use_ring == 9 ||
                      ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
     const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
-    if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1)) ns_gemm_p8_launch(d, st);
+    // the persistent form (one workgroup per CU walks its tiles, epilogue / next-prologue overlap) where its 32-bit epilogue addressing
+    // applies and a workgroup gets at least two tiles; mode 4 forces the one-tile-per-workgroup form (A/B runs)
+    if (big && p8_ok && g_use_ring == 1 && tiles256 >= 512 && !(d->flags & (1 << 27)) && ns_gemm_p8s_ok(d)) ns_gemm_p8s_launch(d, st);
+    else if (big && p8_ok && g_use_ring == 9 && ns_gemm_p8s_ok(d)) ns_gemm_p8s_launch(d, st);
+    else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) ns_gemm_p8_launch(d, st);
     else {
       // only ns_gemm_p8_kernel forms the side product: any other kernel would leave side_out unwritten and the caller's
       // ns_gemm_side_reduce would sum garbage -- refuse instead (e.g. a shape past ns_gemm_p8_fits' 2 GiB limit)

@@ -1,0 +1,589 @@
+// ns_gemm NT, large-M form, PERSISTENT phase-interleaved kernel: the tile arithmetic of ns_gemm_p8.hip (256 x 256 tile, 8 waves,
+// four 16-MFMA phases per K tile, LDS-DMA ring of two 64 KiB buffers -- see that file for the ring, its swizzle and the
+// second (LoRA) product), with one workgroup per CU walking several output tiles so that one tile's epilogue carries the next
+// tile's prologue.  Same products in the same order as ns_gemm_p8_kernel: outputs are bit-identical (tests/test_kernels_gpu.py).
+//   * The epilogue stages the tile in two 128-row halves (the accumulator halves ah = 0 / 1 of every wave) through the 66 KiB
+//     that start at ring buffer 1, so ring buffer 0 is free from the moment the main loop ends: the four regions of the NEXT
+//     tile's first K tile (8 DMA pieces per wave) and its 256 bias values (a ninth piece, into a 1-KiB LDS slot) are requested
+//     between the conversions of the first half and land under the stores.  The remaining two regions (K tile 1 -> buffer 1)
+//     and the second product's fragments follow the last store.
+//   * A tile's set-up, its prologue latency (6.1 k of 41 k cycles in the one-tile form at K = 512) and the workgroup launch are paid
+//     once per CU; what the half-wise epilogue costs more than the whole-tile one (two more barriers, 4.8 k + 5.9 k against 3.0 k +
+//     5.9 k cycles) takes most of it back: 36-37 k cycles per K = 512 tile against 41 k, 0-8 % per launch on the step's shapes.
+//   * Per-tile address arithmetic is re-derived from laundered copies of tid and of the row-map divisors: hipcc otherwise hoists
+//     the tile loop's invariants (lane offsets, division reciprocals) above the loop and spills them -- a scratch reload in the
+//     epilogue is a VMEM operation that waits for every store before it.  Epilogue accesses are scalar base + 32-bit offset.
+//   * No position-row add (the conv2 epilogue stays on ns_gemm_p8_kernel), destinations below 4 GiB (ns_gemm_p8s_ok).
+// Tiles of one XCD's range are dealt round-robin to that XCD's workgroups (same L2 sharing as the one-tile-per-workgroup map).
+#include "ns_gemm_epi.h"
+#include <mutex>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NTH = 512;
+constexpr int REGION = 128 * 128;            // 16 KiB
+constexpr int BUF = 4 * REGION;              // 64 KiB
+constexpr int RA0 = 0, RA1 = 1, RB0 = 2, RB1 = 3;
+constexpr int LDH = BN * 2 + 16;             // epilogue: bytes per staged fp16 row
+constexpr int HALF_BYTES = 128 * LDH;        // 66 KiB: one staged half (128 rows)
+constexpr int SIDE_OFF = BUF + HALF_BYTES + 2048;   // 132 KiB
+constexpr int SIDE_BYTES = 32 * 256 * 2;     // side product: the 32 x 256 slice of side_B of this tile's columns
+constexpr int BIAS_OFF = SIDE_OFF + SIDE_BYTES;     // two 2-KiB slots (tile parity): this tile's 256 bias values, fetched by LDS-DMA one tile ahead
+constexpr int LDS_BYTES = BIAS_OFF + 2 * 2048;      // 152 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define NS_P8_BARRIER()                         \
+  do {                                          \
+    asm volatile("" ::: "memory");              \
+    __builtin_amdgcn_s_barrier();               \
+    asm volatile("" ::: "memory");              \
+  } while (0)
+
+template <int V> struct p8_int_c { static constexpr int value = V; };
+
+// epilogue addressing in 32 bits: element offset of a row (< 2^30 elements, checked by ns_gemm_p8s_fits), and accesses as
+// scalar base + 32-bit byte offset (one address register per access instead of two)
+__device__ __forceinline__ uint32_t rm_off32(const ns_rowmap& m, int row) {
+  if (m.seg_rows > 0) {
+    const int s = row / m.seg_rows;
+    const int w = row - s * m.seg_rows;
+    return (uint32_t)s * (uint32_t)m.seg_stride + (uint32_t)w * (uint32_t)m.ld;
+  }
+  return (uint32_t)row * (uint32_t)m.ld;
+}
+template <class T>
+__device__ __forceinline__ T ld32(const void* base, uint32_t byte_off) { return *(const T*)((const char*)base + byte_off); }
+template <class T>
+__device__ __forceinline__ void st32(void* base, uint32_t byte_off, const T& v) { *(T*)((char*)base + byte_off) = v; }
+
+#ifdef NS_P8_STAMPS
+#define NS_STAMP(i) do { if (stamps && tid == 0) { stamps[(xstart + ti) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define NS_STAMP(i) do { } while (0)
+#endif
+
+template <bool DROP, int KIND>
+__global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef NS_P8_STAMPS
+  ns_gemm_desc p = p_in;
+  unsigned long long* const stamps = (p_in.flags & (1 << 27)) ? (unsigned long long*)p_in.C32 : nullptr;
+  if (stamps) p.C32 = nullptr;
+#else
+  const ns_gemm_desc& p = p_in;
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  // XCD x owns the contiguous tile range [xstart, xstart + xcount); its workgroups (blockIdx % 8 == x) take every nx-th tile of it
+  const int nx = gridDim.x >> 3;
+  int xstart, xcount, ti;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    xstart = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xcount = q + (xcd < r ? 1 : 0);
+    ti = bid >> 3;
+  }
+  if (ti >= xcount) return;
+
+  const int nsteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x80000000u, 0x00020000);
+  // bias of a tile's 256 columns -> LDS, one 4-B element per lane: waves 0..3 fetch the four 64-column groups, waves 4..7 a second
+  // (unread) copy so that every wave's vmcnt sees the same number of pieces.  Columns past N and a null bias read as zeros (range check).
+  const __amdgpu_buffer_rsrc_t rsrc_bias =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.A), 0, p.bias ? 4u * (uint32_t)p.N : 0u, 0x00020000);
+  auto stage_bias = [&](int n0, int slot, int lane) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_bias, (lds_void*)(smem + BIAS_OFF + slot * 2048 + wave * 256), 4,
+                                             4u * (uint32_t)(n0 + 64 * (wave & 3) + lane), 0, 0, 0);
+  };
+
+  // DMA sources of the current / next tile.  Wave w fills region rows [16w, 16w+16) as two 1-KiB pieces (8 rows x 128 B).
+  uint32_t a_src[2][2], b_src[2][2];
+  int my_chunk[2];
+  int src_n0 = 0;
+  auto set_src = [&](int wtile, int lane) __attribute__((always_inline)) {
+    // divisors laundered: their reciprocals are formed here, per tile, not above the tile loop (where they would be spilled)
+    ns_rowmap am = p.am;
+    int tn_div = tiles_n;
+    asm volatile("" : "+s"(am.seg_rows), "+s"(tn_div));
+    const int tm_ = wtile / tn_div;
+    const int m0 = tm_ * BM, n0 = (wtile - tm_ * tn_div) * BN;
+    src_n0 = n0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = 16 * wave + 8 * j + (lane >> 3);
+      my_chunk[j] = (lane & 7) ^ ((rr >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int arow = ((rr >> 6) << 7) + h * 64 + (rr & 63);
+        const int brow = ((rr >> 5) << 6) + h * 32 + (rr & 31);
+        a_src[h][j] = rm_off32(am, min(m0 + arow, p.M - 1)) + (uint32_t)(my_chunk[j] * 8);      // element offsets < 2^30 (ns_gemm_p8_fits)
+        b_src[h][j] = (uint32_t)min(n0 + brow, p.N - 1) * (uint32_t)p.bm.ld + (uint32_t)(my_chunk[j] * 8);
+      }
+    }
+  };
+  auto stage1 = [&](int region, int j) __attribute__((always_inline)) {     // one piece of K tile 0 -> ring buffer 0
+    const int h = region & 1;
+    const bool isb = region >= 2;
+    const uint32_t off = isb ? b_src[h][j] : a_src[h][j];
+    const bool ok = my_chunk[j] * 8 < p.K;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isb ? rsrc_b : rsrc_a, (lds_void*)(smem + region * REGION + wave * 2048 + j * 1024), 16,
+                                             ok ? 2u * off : 0x80000000u, 0, 0, 0);
+  };
+  auto stage = [&](int tt, int region, int buf) __attribute__((always_inline)) {
+    const int k0 = tt * BK;
+    const int klen = p.K - k0;              // <= 0 past the end (padding tiles): fetched as zeros
+    const int h = region & 1;
+    const bool isb = region >= 2;
+    char* const dst = smem + buf * BUF + region * REGION + wave * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t off = isb ? b_src[h][j] : a_src[h][j];
+      const bool ok = my_chunk[j] * 8 < klen;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isb ? rsrc_b : rsrc_a, (lds_void*)(dst + j * 1024), 16, ok ? 2u * off : 0x80000000u,
+                                               2 * k0, 0, 0);
+    }
+  };
+
+  const int fsw = ((lg ^ (l15 >> 1)) & 7) << 4;
+  const int a_base = (wm * 64 + l15) * 128 + fsw;
+  const int b_base = (wn * 32 + l15) * 128 + fsw;
+
+  f32x4 acc[2][4][2][2];
+  half8 af[4][2], bq[2][2][2];
+  auto read_a = [&](int buf, int ah) __attribute__((always_inline)) {
+    const char* st = smem + buf * BUF + (ah ? RA1 : RA0) * REGION;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const half8*)(st + ((a_base ^ (ks << 6)) + mt * 2048));
+  };
+  auto read_b = [&](int buf, int bh) __attribute__((always_inline)) {
+    const char* st = smem + buf * BUF + (bh ? RB1 : RB0) * REGION;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bq[bh][nt][ks] = *(const half8*)(st + ((b_base ^ (ks << 6)) + nt * 2048));
+  };
+  auto mma = [&](int ah, int bh) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[ah][mt][bh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[bh][nt][ks], af[mt][ks], acc[ah][mt][bh][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define NS_P8S_RUN(AH, BH)                                  \
+  do {                                                      \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    NS_P8_BARRIER();                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    mma(AH, BH);                                            \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    NS_P8_BARRIER();                                        \
+  } while (0)
+  auto tile = [&](int t, int b) __attribute__((always_inline)) {
+    read_b(b, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(b, 0);
+    stage(t + 1, RB1, b ^ 1);
+    NS_P8S_RUN(0, 0);
+    read_b(b, 1);
+    stage(t + 1, RA1, b ^ 1);
+    NS_P8S_RUN(0, 1);
+    read_a(b, 1);
+    stage(t + 2, RA0, b);
+    NS_P8S_RUN(1, 1);
+    stage(t + 2, RB0, b);
+    NS_P8S_RUN(1, 0);
+  };
+
+  const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
+  char* const hs = smem + BUF;          // staged half tile
+  char* const sbs = smem + SIDE_OFF;    // side_B slice
+
+  // ---- first tile: full prologue
+  set_src(xstart + ti, lane);
+  stage_bias(src_n0, 0, lane);
+  stage(0, RA0, 0); stage(0, RB0, 0); stage(0, RB1, 0); stage(0, RA1, 0);
+  stage(1, RA0, 1); stage(1, RB0, 1);
+  int par = 0;    // bias slot of the current tile
+
+  for (;;) {
+    // lane-derived values are re-derived per tile from a laundered copy of tid: hipcc would otherwise hoist this tile loop's
+    // invariant address arithmetic (second product, epilogue) above the loop and carry it through the main loop in registers
+    int tid_k = tid;
+    asm volatile("" : "+v"(tid_k));
+    const int lane = tid_k & 63, l15 = lane & 15, lg = lane >> 4;
+    NS_STAMP(0);
+    const int wgid = xstart + ti;
+    int tn_div = tiles_n, a2g = p.a2_ngroup;
+    ns_rowmap am2 = p.am2;
+    asm volatile("" : "+s"(tn_div), "+s"(a2g), "+s"(am2.seg_rows));
+    const int tm = wgid / tn_div, tn = wgid - tm * tn_div;
+    const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- second product (LoRA up-projection, K2 = 16 .. 96): fragments straight from global memory, requested BEHIND the
+    // DMA pieces in flight (their wait therefore also covers the prologue, which phase 1 needs anyway)
+    if (p.K2 > 0) {
+      half8 a2f[2][4], b2f[2][2];
+      uint32_t a2o[2][4], b2o[2][2];     // byte offsets from A2 / B2 (< 2^32: ns_gemm_p8s_ok)
+      const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int goff = a2g > 0 ? ((n0 + wn * 64) / a2g) * p.K2 : 0;
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int row = min(m0 + wm * 128 + ah * 64 + mt * 16 + l15, p.M - 1);
+          a2o[ah][mt] = 2u * (rm_off32(am2, row) + (uint32_t)goff);
+        }
+#pragma unroll
+      for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int col = min(n0 + wn * 64 + bh * 32 + nt * 16 + l15, p.N - 1);
+          b2o[bh][nt] = 2u * ((uint32_t)col * (uint32_t)p.ldb2);
+        }
+      for (int k0 = 0; k0 < p.K2; k0 += 32) {
+        const bool ok = k0 + 8 * lg < p.K2;
+        const int ko = ok ? k0 + 8 * lg : 0;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(a2f[ah][mt]) : "v"(a2o[ah][mt] + 2u * (uint32_t)ko), "s"(p.A2) : "memory");
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b2f[bh][nt]) : "v"(b2o[bh][nt] + 2u * (uint32_t)ko), "s"(p.B2) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(a2f[0][0]), "+v"(a2f[0][1]), "+v"(a2f[0][2]), "+v"(a2f[0][3]), "+v"(a2f[1][0]), "+v"(a2f[1][1]),
+                       "+v"(a2f[1][2]), "+v"(a2f[1][3]), "+v"(b2f[0][0]), "+v"(b2f[0][1]), "+v"(b2f[1][0]), "+v"(b2f[1][1])
+                     :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!ok) {
+#pragma unroll
+          for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a2f[ah][mt] = hz;
+        }
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[ah][mt][bh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2f[bh][nt], a2f[ah][mt], acc[ah][mt][bh][nt], 0, 0, 0);
+      }
+      if (DROP) {
+        // LoRA-dropout mask on the (A2, B2) product, before the main product accumulates on top
+        const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
+        const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const uint32_t row = (uint32_t)(m0 + wm * 128 + a * 64 + i * 16 + l15);
+                const uint32_t col = (uint32_t)(n0 + wn * 64 + bb * 32 + j * 16 + 4 * lg);
+                const uint32_t w = ns_drop_word(dseed, row, col >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][i][bb][j][e] = ns_keep(w, e, drop_thr) ? acc[a][i][bb][j][e] : 0.f;
+              }
+      }
+    }
+    // only RA0 / RB0 of K tile 0 must have landed: phase 1 reads nothing else, and the in-loop vmcnt(8) of phases 1 and 2
+    // retires RB1 / RA1 one phase before they are read
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    NS_P8_BARRIER();
+    NS_STAMP(1);
+    if (wm == 1) NS_P8_BARRIER();     // group 1 runs one barrier interval behind group 0
+    for (int t = 0; t < nsteps; t += 2) {
+      tile(t, 0);
+      tile(t + 1, 1);
+    }
+    if (wm == 0) NS_P8_BARRIER();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-chunk DMA must not land on the staged tile / the next prologue
+    NS_P8_BARRIER();
+    NS_STAMP(2);
+
+    // ---- epilogue in two 128-row halves (half hh = accumulator half ah of every wave; staged row rl -> tile row (rl>>6)*128 + hh*64 + (rl&63))
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, l15e = lane_e & 15, lge = lane_e >> 4;
+    const int ecg = tid_e & 31, er0 = tid_e >> 5;
+    ns_rowmap c16m = p.c16m, g16m = p.g16m, p16m = p.p16m, h32m = p.h32m;
+    int pos_rows = p.pos_rows;
+    asm volatile("" : "+s"(c16m.seg_rows), "+s"(g16m.seg_rows), "+s"(p16m.seg_rows), "+s"(h32m.seg_rows), "+s"(pos_rows));
+    const int tnext = ti + nx;
+    const bool has_next = tnext < xcount;
+    const int ecol = n0 + ecg * 8;
+    const bool ecolok = ecol + 8 <= p.N;
+    const int ecolc = min(ecol, p.N - 8);
+    half_t* const C16 = (half_t*)p.C16;
+    half_t* const G16 = (half_t*)p.G16;
+    const half_t* const P16 = (const half_t*)p.P16;
+    const bool do_gelu = p.flags & NS_GEMM_GELU;
+    const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
+    const bool side = KIND == NS_EPI_PLAIN && p.side_B != nullptr;
+    const uint32_t side_thr = (side && p.side_drop_p > 0.f) ? ns_drop_thr8(p.side_drop_p) : 0u;
+    const uint32_t side_dseed = side_thr ? ns_eff_seed(p.side_drop_seed, p.seed_dev) : 0u;
+    f32x4 res[KIND == NS_EPI_RES ? 8 : 1][2];     // one half at a time (the half-1 rows are requested when half 0's are consumed)
+    half8 pre[KIND == NS_EPI_DGELU ? 16 : 1];
+    float4 bz[2][2];
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        bz[bh][nt] = *(const float4*)(smem + BIAS_OFF + par * 2048 + (wn * 64 + bh * 32 + nt * 16 + 4 * lge) * 4);
+      }
+    auto grow = [&](int hh, int rl) __attribute__((always_inline)) { return m0 + ((rl >> 6) << 7) + hh * 64 + (rl & 63); };
+    auto prefetch = [&](int hh) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = min(grow(hh, er0 + 16 * i), p.M - 1);
+        if (KIND == NS_EPI_RES) {
+          const uint32_t oh = 4u * (rm_off32(h32m, row) + (uint32_t)ecolc);
+          res[i][0] = p.R32 ? ld32<f32x4>(p.R32, oh) : f32x4{0.f, 0.f, 0.f, 0.f};
+          res[i][1] = p.R32 ? ld32<f32x4>(p.R32, oh + 16u) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (KIND == NS_EPI_DGELU) pre[hh * 8 + i] = ld32<half8>(P16, 2u * (rm_off32(p16m, row) + (uint32_t)ecolc));
+      }
+    };
+    // half 0 carries the next tile's first K tile (-> ring buffer 0, dead since the main loop ended) and its bias values: one piece after
+    // every second accumulator group, so the requests drain through the address pipe under the conversions instead of in one burst
+    auto stage_half = [&](int hh) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (KIND != NS_EPI_RES && hh == 0 && has_next && nt == 0) {
+              const int pc = mt * 2 + bh;     // 0 .. 7: RA0, RB0, RB1, RA1 (the order phase 1 .. 3 read them), two pieces each
+              stage1(pc < 2 ? RA0 : (pc < 4 ? RB0 : (pc < 6 ? RB1 : RA1)), pc & 1);
+              if (pc == 7) stage_bias(src_n0, par ^ 1, lane_e);
+            }
+            const int rl = wm * 64 + mt * 16 + l15e;
+            const int cl = wn * 64 + bh * 32 + nt * 16 + 4 * lge;
+            const f32x4 a = acc[hh][mt][bh][nt];
+            const half4 h = {(half_t)(a[0] * alpha + bz[bh][nt].x), (half_t)(a[1] * alpha + bz[bh][nt].y),
+                             (half_t)(a[2] * alpha + bz[bh][nt].z), (half_t)(a[3] * alpha + bz[bh][nt].w)};
+            *(half4*)(hs + rl * LDH + cl * 2) = h;
+          }
+    };
+    auto finish_half = [&](int hh) __attribute__((always_inline)) {
+      // this thread's 8 staged rows first (one LDS round trip, not eight)
+      half8 vst[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vst[i] = *(const half8*)(hs + (er0 + 16 * i) * LDH + ecg * 16);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        {
+          const int rl = er0 + 16 * i, row = grow(hh, rl);
+          if (!ecolok || row >= p.M) continue;
+          half8 v = vst[i];
+          if (KIND == NS_EPI_DGELU) {
+            if (mulp) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * (float)pre[hh * 8 + i][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * ns_gelu_grad((float)pre[hh * 8 + i][e]));
+            }
+          }
+          half8 gv = v, cv = v;
+          if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              ns_f2 g_, dg_;
+              ns_gelu_both2(ns_f2{(float)v[e], (float)v[e + 1]}, g_, dg_);
+              gv[e] = (half_t)g_.x; gv[e + 1] = (half_t)g_.y;
+              if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
+            }
+          }
+          if (C16) st32<half8>(C16, 2u * (rm_off32(c16m, row) + (uint32_t)ecol), cv);
+          if (G16) st32<half8>(G16, 2u * (rm_off32(g16m, row) + (uint32_t)ecol), gv);
+          if (side) {
+            // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged half, LoRA-dropout
+            // mask applied, for the MFMA pass below
+            uint4 w = __builtin_bit_cast(uint4, gv);
+            if (side_thr) {
+              uint32_t mk[4];
+              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
+              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
+              w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
+            }
+            *(uint4*)(hs + rl * LDH + ecg * 16) = w;
+          }
+          if (KIND == NS_EPI_RES) {
+            f32x4 h0 = res[i][0], h1 = res[i][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h0[e] += (float)gv[e]; h1[e] += (float)gv[4 + e]; }
+            const uint32_t oh = 4u * (rm_off32(h32m, row) + (uint32_t)ecol);
+            st32<f32x4>(p.H32, oh, h0);
+            st32<f32x4>(p.H32, oh + 16u, h1);
+          }
+        }
+      }
+      if (side) {
+        // side_out[tn][m][j] = sum_n gm[m][n] side_B[j][n0 + n] over this tile's 256 columns: wave w takes staged rows 16 w .. 16 w + 15
+        // x 32 adapter rows (two 16-row tiles) x 8 steps of 32 columns; side_B on the MFMA A port (a lane owns 4 consecutive j of a row)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        NS_P8_BARRIER();
+        float* const slab = p.side_out + ((long long)tn * p.M) * 32;
+        const int rl = 16 * wave + l15e;
+        f32x4 su[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ss = 0; ss < 8; ++ss) {
+          const half8 gm = *(const half8*)(hs + rl * LDH + (32 * ss + 8 * lge) * 2);
+          const half8 s0 = *(const half8*)(sbs + l15e * 512 + (((4 * ss + lge) ^ l15e) << 4));
+          const half8 s1 = *(const half8*)(sbs + (16 + l15e) * 512 + (((4 * ss + lge) ^ l15e) << 4));
+          su[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s0, gm, su[0], 0, 0, 0);
+          su[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(s1, gm, su[1], 0, 0, 0);
+        }
+        const int row = grow(hh, rl);
+        if (row < p.M) {
+          *(f32x4*)(slab + (long long)row * 32 + 4 * lge) = su[0];
+          *(f32x4*)(slab + (long long)row * 32 + 16 + 4 * lge) = su[1];
+        }
+      }
+    };
+
+    if (side) {
+      // this tile's 32 x 256 slice of side_B, once per tile; 16-B chunk c of row j sits at chunk c ^ (j & 15)
+      const half_t* const SB = (const half_t*)p.side_B + n0 + (tid & 31) * 8;
+      const uint4 sb0 = *(const uint4*)(SB + (long long)(tid >> 5) * p.side_ldb);
+      const uint4 sb1 = *(const uint4*)(SB + (long long)(16 + (tid >> 5)) * p.side_ldb);
+      const int j = tid >> 5, c = tid & 31;
+      *(uint4*)(sbs + j * 512 + ((c ^ (j & 15)) << 4)) = sb0;
+      *(uint4*)(sbs + (16 + j) * 512 + ((c ^ (j & 15)) << 4)) = sb1;
+    }
+    prefetch(0);
+    if (KIND != NS_EPI_RES && has_next) set_src(xstart + tnext, lane_e);
+    NS_STAMP(7);
+    stage_half(0);
+    NS_STAMP(10);
+    if (KIND == NS_EPI_RES && has_next) {     // (the residual form has no registers to spare for the next tile's addresses before half 0 is staged)
+      set_src(xstart + tnext, lane_e);
+      stage(0, RA0, 0); stage(0, RB0, 0); stage(0, RB1, 0); stage(0, RA1, 0);
+      stage_bias(src_n0, par ^ 1, lane_e);
+    }
+    if (KIND != NS_EPI_RES) prefetch(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NS_P8_BARRIER();
+    NS_STAMP(3);
+    // half 0's loads are older than the next tile's pieces and half 1's loads: settle them by count
+    if (KIND == NS_EPI_RES) {
+      if (has_next) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(res[i][0])); asm volatile("" : "+v"(res[i][1])); }
+    }
+    if (KIND == NS_EPI_DGELU) {
+      if (has_next) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pre[i]));
+    }
+    finish_half(0);
+    NS_STAMP(4);
+    if (KIND == NS_EPI_RES) prefetch(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NS_P8_BARRIER();
+    stage_half(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NS_P8_BARRIER();
+    NS_STAMP(5);
+    if (KIND == NS_EPI_RES) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(res[i][0])); asm volatile("" : "+v"(res[i][1])); }
+    }
+    if (KIND == NS_EPI_DGELU) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 8; i < 16; ++i) asm volatile("" : "+v"(pre[i]));
+    }
+    finish_half(1);
+    NS_STAMP(6);
+    if (!has_next) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NS_P8_BARRIER();          // every wave is done with the staged half: ring buffer 1 may be refilled
+    stage(1, RA0, 1); stage(1, RB0, 1);
+    ti = tnext;
+    par ^= 1;
+  }
+}
+
+template <bool DROP>
+void launch_kind(const ns_gemm_desc* d, int grid, hipStream_t st) {
+  const int kind = d->H32 ? NS_EPI_RES : ((d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) ? NS_EPI_DGELU : NS_EPI_PLAIN);
+  if (kind == NS_EPI_RES) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_RES>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else if (kind == NS_EPI_DGELU) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_DGELU>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+}
+
+}  // namespace
+
+// the epilogue addresses its fp32 / fp16 destinations with 32-bit byte offsets, and has no position-row add
+bool ns_gemm_p8s_ok(const ns_gemm_desc* d) {
+  const auto extent = [](const ns_rowmap& m, int rows, int n) -> long long {
+    const long long last = m.seg_rows > 0 ? (long long)((rows - 1) / m.seg_rows) * m.seg_stride + (long long)((rows - 1) % m.seg_rows) * m.ld
+                                          : (long long)(rows - 1) * m.ld;
+    return last + n + 16;
+  };
+  if (d->pos) return false;
+  if (d->K2 > 0 && (2 * extent(d->am2, d->M, d->K2 * 3) >= 0xFFFF0000LL || 2LL * d->N * d->ldb2 >= 0xFFFF0000LL)) return false;
+  if (d->H32 && 4 * extent(d->h32m, d->M, d->N) >= 0xFFFF0000LL) return false;
+  if (d->C16 && 2 * extent(d->c16m, d->M, d->N) >= 0xFFFF0000LL) return false;
+  if (d->G16 && 2 * extent(d->g16m, d->M, d->N) >= 0xFFFF0000LL) return false;
+  if (d->P16 && 2 * extent(d->p16m, d->M, d->N) >= 0xFFFF0000LL) return false;
+  return true;
+}
+
+int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st) {
+  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  static std::once_flag attr_once;   // lazily created immutable kernel attributes: std::call_once (include/neuspeech_hip.h, threading)
+  static int cus_per_xcd = 32;
+  std::call_once(attr_once, [&] {
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
+      cus_per_xcd = cus / 8;
+  });
+  // one workgroup per CU (148 KiB of LDS, 512 threads x 256 registers: nothing else fits beside it), 8 XCDs round-robin
+  const int per_xcd = std::min(cus_per_xcd, (tiles + 7) / 8);
+  if (d->drop_p > 0.f) launch_kind<true>(d, 8 * per_xcd, st);
+  else launch_kind<false>(d, 8 * per_xcd, st);
+  return 0;
+}

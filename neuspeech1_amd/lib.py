@@ -241,6 +241,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.ns_version() != ABI_VERSION:
         raise NeuSpeechHipError(f"ABI version mismatch: {lib.ns_version()}")
+    if os.environ.get("NS_GEMM_MODE"):   # same-box A/B runs of the GEMM kernel variants (ns_debug_set_ring: 1 = auto, 4 = one tile per workgroup, ...)
+        lib.ns_debug_set_ring(int(os.environ["NS_GEMM_MODE"]))
     _lib = lib
     return lib
 

@@ -51,9 +51,10 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path):
-    kernels = {k: v for k, v in _kernels(_asm("ns_gemm_p8.hip", tmp_path)).items() if "ns_gemm_p8_kernel" in k}
-    assert len(kernels) == 2, list(kernels)
+@pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 6)])
+def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, kernel, count):
+    kernels = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
+    assert len(kernels) == count, list(kernels)
     for name, body in kernels.items():
         pending, in_asm, checked = set(), False, 0
         for line in body:
@@ -107,3 +108,26 @@ def test_one_pass_attention_backward_steady_state_has_no_scratch_and_one_vmem_wa
     assert n_mfma >= 48, n_mfma                      # 2 halves x (8 + 8 big + 8 small)
     assert not re.search(r"scratch_(load|store)", loop)
     assert len(re.findall(r"s_waitcnt vmcnt", loop)) <= 2
+
+
+def test_persistent_gemm_k_loop_has_no_scratch(tmp_path):
+    """ns_gemm_p8s_kernel: the residual-epilogue variants spill a few tile addresses ACROSS the epilogue (stored after the main loop,
+    reloaded before the next one); the K loop itself -- the depth-2 loop that holds the 128 main-product MFMAs, with its hand-counted
+    vmcnt(8) waits -- must not touch scratch in any variant, and must not wait for an empty vector-memory queue."""
+    ks = {k: v for k, v in _kernels(_asm("ns_gemm_p8s.hip", tmp_path)).items() if "ns_gemm_p8s_kernel" in k}
+    assert len(ks) == 6
+    for name, body in ks.items():
+        text = "\n".join(body)
+        loops = [m.start() for m in re.finditer(r"Inner Loop Header: Depth=2", text)]
+        found = False
+        for st in loops:
+            loop = text[st:]
+            end = re.search(r"s_cbranch_\w+ \.LBB\d+_\d+\n", loop)
+            loop = loop[:end.end()] if end else loop[:80000]
+            if len(re.findall(r"v_mfma_", loop)) < 128:
+                continue
+            found = True
+            assert not re.search(r"scratch_(load|store)", loop), name
+            assert "vmcnt(0)" not in loop, name
+            assert len(re.findall(r"s_barrier", loop)) == 16, name     # two K tiles x four phases x two barriers
+        assert found, f"{name}: K loop not found"

@@ -869,3 +869,74 @@ def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
     ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C32=C, ldc32=N, splits=splits)
     ref = A.float() @ B.float().T
     close(C, ref, 2e-3, 2e-3, "split-K NT")
+
+
+def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
+    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 512 tiles) against ns_gemm_p8 (one tile per
+    workgroup) on ragged shapes with > 256 tiles, so that workgroups really carry the next tile's prologue through an epilogue:
+    every epilogue kind, second product (ragged column groups, LoRA dropout), segmented row maps with an in-place residual, the
+    GELU side product.  Same arithmetic in the same order: outputs must be bit-identical."""
+    from neuspeech1_amd import lib
+    M, N, K, r = 256 * 90 + 40, 760, 208, 32
+    A, B = rnd((M, K), dev, seed=1), rnd((N, K), dev, 0.1, seed=2)
+    bias = rnd((N,), dev, 0.2, torch.float32, seed=3)
+    R = rnd((M, N), dev, 1.0, torch.float32, seed=4)
+    P = rnd((M, N), dev, 1.0, seed=6)
+    u, Bs = rnd((M, 2 * r), dev, 0.5, seed=7), rnd((N, r), dev, 0.1, seed=8)
+    u3, B3 = rnd((M, 3 * r), dev, 0.5, seed=12), rnd((N, 3 * r), dev, 0.1, seed=13)
+    Cin, T2, segs = 48, 3000, 8
+    Rc = rnd((segs * T2, N), dev, 1.0, torch.float32, seed=11)
+    img = rnd((segs, 2 * T2 + 2, Cin), dev, 1.0, seed=9)
+    Wc = rnd((N, 3 * Cin), dev, 0.1, seed=10)
+    Ns = 768
+    Bside, sideB = rnd((Ns, K), dev, 0.1, seed=14), rnd((32, Ns), dev, 0.1, seed=15)
+    nan16 = lambda n: torch.full((M, n), float("nan"), device=dev, dtype=torch.float16)
+
+    def run():
+        out = {}
+        C16, G16 = nan16(N), nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, C16=C16, c16m=ops.rowmap(N), G16=G16, g16m=ops.rowmap(N),
+                 flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD)
+        out["gelu_save"] = (C16, G16)
+        H = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, bias=bias, R32=R, H32=H, h32m=ops.rowmap(N),
+                 A2=u, am2=ops.rowmap(2 * r), K2=r, B2=Bs, ldb2=r, a2_ngroup=384, drop_p=0.05, drop_seed=5)
+        out["res_second_drop"] = (H,)
+        D = nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N),
+                 flags=ops.NS_GEMM_MUL_P16, alpha=0.5, A2=u3, am2=ops.rowmap(3 * r), K2=3 * r, B2=B3, ldb2=3 * r)
+        out["mul_p16_k2_96"] = (D,)
+        D2 = nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=D2, c16m=ops.rowmap(N), P16=P, p16m=ops.rowmap(N), flags=ops.NS_GEMM_DGELU)
+        out["dgelu"] = (D2,)
+        E = nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(2 * r), K2=16, B2=Bs, ldb2=r, a2_ngroup=384, C16=E, c16m=ops.rowmap(N))
+        out["second_k2_16"] = (E,)
+        Hc = Rc.clone()
+        ops.gemm(A=(img, 0), am=ops.rowmap(2 * Cin, T2, (2 * T2 + 2) * Cin), K=3 * Cin, B=Wc, ldb=3 * Cin, M=segs * T2, N=N,
+                 bias=bias, R32=Hc, H32=Hc, h32m=ops.rowmap(N))
+        out["conv_res_inplace"] = (Hc,)
+        Cs, Gs = nan16(Ns), nan16(Ns)
+        slab = torch.full((Ns // 256, M, 32), float("nan"), device=dev)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=Bside, ldb=K, M=M, N=Ns, bias=bias[:Ns].contiguous(), C16=Cs, c16m=ops.rowmap(Ns), G16=Gs, g16m=ops.rowmap(Ns),
+                 flags=ops.NS_GEMM_GELU | ops.NS_GEMM_GELU_SAVE_GRAD, side_B=sideB, side_ldb=Ns, side_n=32, side_out=slab, side_drop_p=0.05,
+                 side_drop_seed=3)
+        out["gelu_side"] = (Cs, Gs, slab)
+        return out
+    try:
+        lib.load().ns_debug_set_ring(4)
+        ref = run()
+        lib.load().ns_debug_set_ring(9)
+        got = run()
+    finally:
+        lib.load().ns_debug_set_ring(1)
+    for k in ref:
+        for a, b in zip(got[k], ref[k]):
+            assert not torch.isnan(a.float()).any(), k
+            assert torch.equal(a, b), (k, int((a != b).sum()))
+    # and the one-tile form against torch where no other test covers the combination (ragged second-product groups under dropout are covered
+    # by test_lora_dropout_*; here the plain second product with K2 = 16)
+    sec = A.float() @ B.float().T
+    sec[:, :384] += u[:, :16].float() @ Bs[:384, :16].float().T
+    sec[:, 384:] += u[:, 16:32].float() @ Bs[384:, :16].float().T      # group g reads columns [g K2, (g + 1) K2) of A2
+    close(ref["second_k2_16"][0], sec, 6e-3, 3e-3, "second product, K2 = 16")

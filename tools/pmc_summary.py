@@ -15,7 +15,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ("ns_gemm_p8.hip", "ns_gemm_epi.h"):
+    for f in ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h"):
         h.update(open(os.path.join(ROOT, "neuspeech1_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -45,10 +45,10 @@ def main():
         n = max(nf, nw, 1)
         out["kernels"][k[:100]] = {"launches": n, "fetch_kb_raw_per_launch": f / max(nf, 1), "write_kb_per_launch": w / max(nw, 1),
                                    "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
-    dom = [v for k, v in out["kernels"].items() if "ns_gemm_p8_kernel" in k]
+    dom = [v for k, v in out["kernels"].items() if "ns_gemm_p8s_kernel" in k or "ns_gemm_p8_kernel" in k]   # persistent form + its one-tile fallback
     if dom:
         n = sum(v["launches"] for v in dom)
-        out["kernel"] = "ns_gemm_p8_kernel"
+        out["kernel"] = "ns_gemm_p8s_kernel"
         out["launches"] = n
         out["hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in dom) / n
     path = os.path.join(OUT, f"pmc_{tag}_traffic.json")

@@ -11,11 +11,11 @@ OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 mode="$1"; tag="$2"; shift 2
 cd /tmp && export TMPDIR=/tmp
-# counter passes run the step EAGERLY (NS_TRAIN_GRAPH=0: same kernels, one dispatch record per launch); the stats pass keeps the
-# default (hipGraph replay), which is what bench.py times
+# every pass runs the step EAGERLY (NS_TRAIN_GRAPH=0: the same kernels with the same arguments, one dispatch record per launch --
+# rocprofv3's kernel trace on this ROCm does not list the kernels of a replayed hipGraph); bench.py's timed loop replays the graph
 case "$mode" in
   stats)
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_$tag.json" 2> "$OUT/prof_$tag.log"
+    NS_TRAIN_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_$tag.json" 2> "$OUT/prof_$tag.log"
     ;;
   pmc)
     for c in FETCH_SIZE WRITE_SIZE; do
