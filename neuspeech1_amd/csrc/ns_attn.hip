@@ -50,16 +50,27 @@ __device__ __forceinline__ half8 tr_frag8(const char* tile, int rbase, int cb, i
 }
 
 // ---- staging helpers (256 threads, tile = 64 rows x 64 halfs) ------------------
-// row-major image: thread handles 2 x 16 B
+// row-major image: thread handles 2 x 16 B.  Lane -> (row, chunk) inside a group of 16 lanes: lanes 0-3 row 2k chunks 0-3, lanes 4-7 row 2k+1
+// chunks 0-3, lanes 8-11 row 2k chunks 4-7, lanes 12-15 row 2k+1 chunks 4-7 -- ds_write_b128 is serviced in groups of 8 consecutive lanes
+// over 32 banks, and chunks c and c + 4 of one row sit 512 B apart (the same banks): one row per 8 lanes was a 2-way conflict on every store
+// (32 LDS cycles per wave and tile in SQ_LDS_BANK_CONFLICT, all of that counter's total); two half-rows per 8 lanes are conflict-free.
+// The global side still covers whole 128-B head rows inside each wave instruction.
+__device__ __forceinline__ void rm_lane(int id, int& row, int& chunk) {
+  const int l16 = id & 15;
+  row = 2 * (id >> 4) + ((l16 >> 2) & 1);
+  chunk = (l16 & 3) + 4 * (l16 >> 3);
+}
 __device__ __forceinline__ void load_rm(const half_t* __restrict__ base, long long ld, int row0, int L, uint4& r0, uint4& r1) {
-  const int id = threadIdx.x;
-  r0 = *(const uint4*)(base + (long long)min(row0 + (id >> 3), L - 1) * ld + (id & 7) * 8);
-  r1 = *(const uint4*)(base + (long long)min(row0 + 32 + (id >> 3), L - 1) * ld + (id & 7) * 8);
+  int row, chunk;
+  rm_lane(threadIdx.x, row, chunk);
+  r0 = *(const uint4*)(base + (long long)min(row0 + row, L - 1) * ld + chunk * 8);
+  r1 = *(const uint4*)(base + (long long)min(row0 + 32 + row, L - 1) * ld + chunk * 8);
 }
 __device__ __forceinline__ void store_rm(char* lds, const uint4& r0, const uint4& r1) {
-  const int id = threadIdx.x;
-  *(uint4*)(lds + lds_off(id >> 3, id & 7)) = r0;
-  *(uint4*)(lds + lds_off(32 + (id >> 3), id & 7)) = r1;
+  int row, chunk;
+  rm_lane(threadIdx.x, row, chunk);
+  *(uint4*)(lds + lds_off(row, chunk)) = r0;
+  *(uint4*)(lds + lds_off(32 + row, chunk)) = r1;
 }
 __device__ __forceinline__ half8 cvt8(const f32x16& x, int base) {
   half8 h;
