@@ -279,7 +279,10 @@ typedef struct {
   /* backward only (ABI 2): with a workspace of ns_attn_bwd_workspace_bytes(...) bytes (> 0 for unmasked attention over
      >= 256 queries and keys) the backward runs in ONE pass -- S and dP formed once, dQ summed over the key sweeps of a
      (batch, head) in this caller-owned fp32 scratch, no atomics (csrc/ns_attn_bwd1.hip) -- instead of the dQ pass +
-     dK/dV pass, which each recompute S and dP.  NULL / 0 keeps the two-pass kernels. */
+     dK/dV pass, which each recompute S and dP.  Also > 0 for unmasked attention with <= 64 queries over >= 256 keys (the
+     decoder's cross-attention): K / V are streamed once, dQ leaves through fp32 slabs in the workspace (one per group of
+     key blocks) that a second launch adds in a fixed order (csrc/ns_attn.hip, attn_bwd_fewq_kernel).  NULL / 0 keeps
+     the two-pass kernels. */
   void* workspace; size_t workspace_bytes;
 } ns_attn_desc;
 int ns_attn_fwd(const ns_attn_desc* d, void* stream);

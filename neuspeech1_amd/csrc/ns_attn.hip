@@ -488,6 +488,218 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const ns_attn_desc
   }
 }
 
+// =============================================================== backward, few queries (<= 64), no mask, ONE pass: the decoder's cross-attention
+// (Lq = label length, Lk = 1500).  Such a launch is bound by streaming K / V in and dK / dV out (392 MB per layer at B = 64 against 17 GFLOP); the
+// two-pass form reads K and V a second time for dQ (59 us of 157 per layer).  Here a workgroup owns KPW blocks of 128 keys (one wave = 32 keys,
+// fragments in registers), holds the (batch, head)'s single 64-query tile of Q and dO in LDS, and per key block
+//   * forms S / dP with the query on the accumulator rows (as attn_bwd_dkv_kernel) for dK^T, dV^T, stored at once;
+//   * forms S^T / dP^T again with the operands swapped (key on the accumulator rows, query on the lane: 16 more MFMAs, nothing next to the streaming),
+//     rounds dS^T to fp16 and writes it to a [query][key] LDS image -- lane half h's accumulator rows 0..7 / 8..15 are exactly the 8 + 8 keys that the
+//     accumulator-as-operand order of tr_frag8 pairs with one k-step, so each is ONE 16-byte store and a plain row read gives the MFMA's B operand;
+//   * after one barrier, wave w adds K^T dS^T of all 128 keys into ITS 32 x 32 piece of dQ^T (d half w & 1, query half w >> 1; K^T through the
+//     transposed read of a [key][d] LDS image written from the key fragments).
+// dQ partial sums of the key-block groups leave as fp32 slabs [group][b][h][q][d] (6 x 5.8 MB at B = 64) and attn_fewq_dq_reduce_kernel adds them
+// in a fixed order and rounds to fp16: bitwise reproducible.  delta = rowsum(dO o O) is formed here too (the dQ pass used to).
+constexpr int FEWQ_KPW = NS_FEWQ_KPW;       // key blocks of 128 per workgroup (ns_common.h)
+__device__ __forceinline__ int dst_off(int q, int chunk) { return q * 256 + ((chunk ^ (q & 15)) << 4); }   // [64 q][128 keys] fp16, conflict-free row reads
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_fewq_kernel(const ns_attn_desc p, float* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512 + 16384 + 16384];
+  char* const Qs = smem;
+  char* const dOs = smem + 8192;
+  float* const lse_s = (float*)(smem + 16384);
+  float* const del_s = lse_s + 64;
+  char* const Kimg = smem + 16384 + 512;
+  char* const dST = Kimg + 16384;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  int bx_, h, b;
+  xcd_block_ids(bx_, h, b);
+  const half_t* Q = (const half_t*)p.Q + (long long)b * p.Lq * p.ldq + h * D;
+  const half_t* K = (const half_t*)p.K + (long long)b * p.Lk * p.ldk + h * D;
+  const half_t* V = (const half_t*)p.V + (long long)b * p.Lk * p.ldv + h * D;
+  const half_t* O = (const half_t*)p.O + (long long)b * p.Lq * p.ldo + h * D;
+  const half_t* dO = (const half_t*)p.dO + (long long)b * p.Lq * p.lddo + h * D;
+
+  {   // the one query tile: Q, dO -> LDS; -lse, -delta (queries past Lq: -inf, their probabilities vanish)
+    uint4 qr0, qr1, dr0, dr1;
+    load_rm(Q, p.ldq, 0, p.Lq, qr0, qr1); load_rm(dO, p.lddo, 0, p.Lq, dr0, dr1);
+    store_rm(Qs, qr0, qr1); store_rm(dOs, dr0, dr1);
+    // delta[q] = sum_d dO[q][d] O[q][d]: 4 threads per query, 16 columns each
+    const int q = threadIdx.x >> 2, part = threadIdx.x & 3, qq = min(q, p.Lq - 1);
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const half8 a = *(const half8*)(dO + (long long)qq * p.lddo + part * 16 + c * 8);
+      const half8 o = *(const half8*)(O + (long long)qq * p.ldo + part * 16 + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)o[j];
+    }
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    if (part == 0) {
+      const long long stat = ((long long)b * p.H + h) * p.Lq + qq;
+      const bool qok = q < p.Lq;
+      lse_s[q] = qok ? -p.LSE[stat] : -INFINITY;
+      del_s[q] = -dl;
+      if (qok && bx_ == 0) p.Delta[stat] = dl;
+    }
+  }
+  __syncthreads();
+
+  const int dt_w = wave & 1, qt_w = wave >> 1;     // this wave's piece of dQ^T
+  f32x16 dqa;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
+
+  // this wave's key fragments, requested one key block ahead (the launch is a chain of load -> products -> store per block otherwise: two
+  // workgroups per CU do not cover a strided fetch from HBM)
+  half8 kf[4], vf[4], kfn[4], vfn[4];
+  auto load_kv = [&](int kb0, half8 (&kk)[4], half8 (&vv)[4]) __attribute__((always_inline)) {
+    const int krow = min(kb0 + wave * 32 + lr, p.Lk - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kk[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
+      vv[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
+    }
+  };
+  load_kv(bx_ * FEWQ_KPW * 128, kfn, vfn);
+  for (int kbi = 0; kbi < FEWQ_KPW; ++kbi) {
+    const int kb0 = (bx_ * FEWQ_KPW + kbi) * 128;
+    if (kb0 >= p.Lk) break;       // block-uniform
+    const int key = kb0 + wave * 32 + lr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = kfn[s]; vf[s] = vfn[s]; }
+    if (kbi + 1 < FEWQ_KPW && kb0 + 128 < p.Lk) load_kv(kb0 + 128, kfn, vfn);
+    // ---- dK^T, dV^T (query on the accumulator rows; the row constants ride in as the initial accumulators)
+    {
+      f32x16 dkt[2], dvt[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkt[t][r] = 0.f; dvt[t][r] = 0.f; }
+      f32x16 st[2], dp[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 nl = *(const float4*)(lse_s + qt * 32 + 8 * g + 4 * lh);
+          const float4 nd = *(const float4*)(del_s + qt * 32 + 8 * g + 4 * lh);
+          st[qt][4 * g + 0] = nl.x; st[qt][4 * g + 1] = nl.y; st[qt][4 * g + 2] = nl.z; st[qt][4 * g + 3] = nl.w;
+          dp[qt][4 * g + 0] = nd.x; dp[qt][4 * g + 1] = nd.y; dp[qt][4 * g + 2] = nd.z; dp[qt][4 * g + 3] = nd.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const half8 aq = *(const half8*)(Qs + lds_off(qt * 32 + lr, 2 * s + lh));
+          const half8 ad = *(const half8*)(dOs + lds_off(qt * 32 + lr, 2 * s + lh));
+          st[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq, kf[s], st[qt], 0, 0, 0);   // S[q][key] - lse[q]
+          dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad, vf[s], dp[qt], 0, 0, 0);   // dP[q][key] - delta[q]
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[qt][r] * LOG2E);
+          st[qt][r] = pv;                 // P
+          dp[qt][r] = pv * dp[qt][r];     // dS
+        }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half8 pb = cvt8(st[qt], 8 * s2);
+          const half8 dsb = cvt8(dp[qt], 8 * s2);
+          const int sg = qt * 2 + s2;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const half8 a1 = tr_frag8(dOs, 16 * sg, dt * 32, lane);
+            const half8 a2 = tr_frag8(Qs, 16 * sg, dt * 32, lane);
+            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb, dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, dsb, dkt[dt], 0, 0, 0);
+          }
+        }
+      if (key < p.Lk) {
+        half_t* dK = (half_t*)p.dK + ((long long)b * p.Lk + key) * p.lddk + h * D;
+        half_t* dV = (half_t*)p.dV + ((long long)b * p.Lk + key) * p.lddv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4 ok_, ov_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ok_[e] = (half_t)dkt[dt][4 * g + e]; ov_[e] = (half_t)dvt[dt][4 * g + e]; }
+            *(half4*)(dK + dt * 32 + 8 * g + 4 * lh) = ok_;
+            *(half4*)(dV + dt * 32 + 8 * g + 4 * lh) = ov_;
+          }
+      }
+    }
+    // ---- dS^T (key on the accumulator rows, query on the lane) -> [query][key] image; this wave's key rows -> [key][d] image
+    {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) *(half8*)(Kimg + lds_off(wave * 32 + lr, 2 * s + lh)) = kf[s];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float nl = lse_s[qt * 32 + lr], nd = del_s[qt * 32 + lr];
+        f32x16 sT, dpT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] = nl; dpT[r] = nd; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const half8 bq = *(const half8*)(Qs + lds_off(qt * 32 + lr, 2 * s + lh));
+          const half8 bd = *(const half8*)(dOs + lds_off(qt * 32 + lr, 2 * s + lh));
+          sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], bq, sT, 0, 0, 0);    // S^T[key][q] - lse[q]
+          dpT = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s], bd, dpT, 0, 0, 0);  // dP^T[key][q] - delta[q]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool kok = kb0 + wave * 32 + crow(r, lh) < p.Lk;      // rows past Lk hold copies of the last key: no contribution to dQ
+          sT[r] = kok ? __builtin_amdgcn_exp2f(sT[r] * LOG2E) * dpT[r] : 0.f;
+        }
+        // accumulator rows 0..7 of lane half h = keys {4h..4h+3, 8+4h..8+4h+3} of the first 16, rows 8..15 the same of the second 16: the k order
+        // tr_frag8 gives the OTHER operand -- stored as positions [8h, 8h+8) of each 16-key group, a row read returns them as the B operand
+        *(half8*)(dST + dst_off(qt * 32 + lr, 4 * wave + lh)) = cvt8(sT, 0);
+        *(half8*)(dST + dst_off(qt * 32 + lr, 4 * wave + 2 + lh)) = cvt8(sT, 8);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const half8 a = tr_frag8(Kimg, 16 * ks, dt_w * 32, lane);                                   // K^T[d][16 keys]
+      const half8 bfr = *(const half8*)(dST + dst_off(qt_w * 32 + lr, 2 * ks + lh));            // dS^T[16 keys][q]
+      dqa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr, dqa, 0, 0, 0);
+    }
+    __syncthreads();      // the images are rewritten by the next key block
+  }
+  // dQ^T[d = 32 dt + crow(r, lh)][q = 32 qt + lr] of this group of key blocks
+  const int q = qt_w * 32 + lr;
+  if (q < p.Lq) {
+    float* const dst = slabs + ((((long long)bx_ * p.B + b) * p.H + h) * p.Lq + q) * D + dt_w * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(float4*)(dst + 8 * g + 4 * lh) = make_float4(dqa[4 * g], dqa[4 * g + 1], dqa[4 * g + 2], dqa[4 * g + 3]);
+  }
+}
+
+// dQ[b][q][h*64 + d] = fp16(sum over the key-block groups, in order): one thread per 4 columns
+__global__ __launch_bounds__(256) void attn_fewq_dq_reduce_kernel(const ns_attn_desc p, const float* __restrict__ slabs, int nslab) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // float4 index inside a slab: ((b H + h) Lq + q) 16 + c
+  const long long per = (long long)p.B * p.H * p.Lq * (D / 4);
+  if (i >= per) return;
+  float4 a = *(const float4*)(slabs + 4 * i);
+  for (int s = 1; s < nslab; ++s) {
+    const float4 v = *(const float4*)(slabs + 4 * (i + s * per));
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int c = (int)(i % (D / 4));
+  const long long row = i / (D / 4);            // (b H + h) Lq + q
+  const int q = (int)(row % p.Lq);
+  const long long bh = row / p.Lq;
+  const int h = (int)(bh % p.H);
+  const long long b = bh / p.H;
+  const half4 o = {(half_t)a.x, (half_t)a.y, (half_t)a.z, (half_t)a.w};
+  *(half4*)((half_t*)p.dQ + (b * p.Lq + q) * p.lddq + h * D + 4 * c) = o;
+}
+
 int check_desc(const ns_attn_desc* d, bool bwd) {
   NS_CHECK_ARG(d, "ns_attn: null descriptor");
   NS_CHECK_ARG(d->head_dim == 64, "ns_attn: head_dim=%d unsupported (only 64)", d->head_dim);
@@ -520,7 +732,17 @@ extern "C" int ns_attn_bwd(const ns_attn_desc* d, void* stream) {
   int rc = check_desc(d, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (d->workspace && ns_attn_bwd_workspace_bytes(d->B, d->H, d->Lq, d->Lk, d->causal) > 0)
+  const size_t ws_need = d->workspace ? ns_attn_bwd_workspace_bytes(d->B, d->H, d->Lq, d->Lk, d->causal) : 0;
+  if (ws_need > 0 && d->Lq <= 64) {      // few queries (the decoder's cross-attention): one pass, dQ through fp32 slabs
+    NS_CHECK_ARG(d->workspace_bytes >= ws_need, "ns_attn_bwd (few queries): workspace of %zu bytes needed, %zu given", ws_need, d->workspace_bytes);
+    const int nslab = (d->Lk + 128 * FEWQ_KPW - 1) / (128 * FEWQ_KPW);
+    hipLaunchKernelGGL(attn_bwd_fewq_kernel, dim3(nslab, d->H, d->B), dim3(256), 0, st, *d, (float*)d->workspace);
+    const long long per = (long long)d->B * d->H * d->Lq * (D / 4);
+    hipLaunchKernelGGL(attn_fewq_dq_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, *d, (const float*)d->workspace, nslab);
+    NS_CHECK_LAUNCH("ns_attn_bwd (few queries)");
+    return NS_OK;
+  }
+  if (ws_need > 0)
     return ns_attn_bwd1_launch(d, d->workspace, d->workspace_bytes, st);   // one pass: csrc/ns_attn_bwd1.hip
   dim3 gq((d->Lq + 127) / 128, d->H, d->B), gk((d->Lk + 127) / 128, d->H, d->B);
   if (d->causal) {

@@ -421,9 +421,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd1_kernel(const ns_attn_desc p, 
 // scratch floats: B * H * ceil(Lq / 64) * 64 * 64
 extern "C" size_t ns_attn_bwd_workspace_bytes(int B, int H, int Lq, int Lk, int causal) {
   // unmasked attention with many queries: the encoder's self-attention.  The decoder's cross-attention (45 queries, 1500 keys:
-  // one step per sweep) was measured 0.200 ms through this kernel against 0.166 ms for the two passes -- six serial sweep
-  // prologues per workgroup and only B x H workgroups; causal / short-key shapes stay with the two-pass kernels as well.
-  if (causal || Lq < 256 || Lk < 256) return 0;
+  // one step per sweep) was measured 0.200 ms through THIS kernel against 0.166 ms for the two passes -- six serial sweep
+  // prologues per workgroup and only B x H workgroups -- and has a one-pass kernel of its own; causal / short-key shapes stay with
+  // the two-pass kernels.
+  if (causal || Lk < 256) return 0;
+  // few queries (the decoder's cross-attention): attn_bwd_fewq_kernel in ns_attn.hip, fp32 dQ slabs, one per group of 128 x NS_FEWQ_KPW keys
+  if (Lq <= 64) return (size_t)((Lk + 128 * NS_FEWQ_KPW - 1) / (128 * NS_FEWQ_KPW)) * B * H * Lq * D * sizeof(float);
+  if (Lq < 256) return 0;
   return (size_t)B * H * ((Lq + QT - 1) / QT) * QT * D * sizeof(float);
 }
 

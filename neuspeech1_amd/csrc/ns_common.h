@@ -13,6 +13,11 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// few-query one-pass attention backward (ns_attn.hip attn_bwd_fewq_kernel): key blocks of 128 per workgroup = keys per fp32 dQ slab / 128
+#ifndef NS_FEWQ_KPW
+#define NS_FEWQ_KPW 4
+#endif
+
 // ---- error plumbing (thread-local message, int status; no exceptions cross the ABI)
 void ns_set_error(const char* fmt, ...);
 

@@ -555,6 +555,9 @@ class MegWhisperEngine:
             b["ddao"] = h16(ML, d)
             b["ddpre_f"] = h16(ML, f)
             b["ddelta"] = f32(B, H, L)
+            # cross-attention backward in one pass (few queries): fp32 dQ slabs, one per group of key blocks (0 bytes: the two-pass kernels)
+            nws = ops.attn_bwd_workspace_bytes(B, H, L, dims.src_pos) if os.environ.get("NS_ATTN_TWO_PASS") != "1" else 0
+            b["attn_ws_c"] = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
         return b
 
     # ------------------------------------------------------------------ helpers
@@ -869,7 +872,7 @@ class MegWhisperEngine:
             kv = b["kv_c"][i]
             ops.attn_bwd(Q=b["q_c"][i], K=kv, V=(kv, d), O=b["ao_c"][i], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
                          ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][i], dO=b["ddao"], dQ=b["ddq_c"], dK=b["dkv_c"],
-                         dV=(b["dkv_c"], d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=2 * d, lddv=2 * d)
+                         dV=(b["dkv_c"], d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=2 * d, lddv=2 * d, workspace=b["attn_ws_c"])
             dgrad("cq", b["ddq_c"], ML, b["xc"][i], 2, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h1, *b["st_c"][i], Lw["ln2"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
             # encoder-state gradient accumulates in fp32 across the decoder layers

@@ -405,6 +405,59 @@ def test_attention_fwd_bwd(ops, dev, Bn, H, Lq, Lk, causal):
     assert dQ[:, d:].abs().max() == 0, "attention must not write outside its head columns"
 
 
+@pytest.mark.parametrize("Bn,H,Lq,Lk,scale", [(3, 2, 44, 1500, 0.3), (1, 3, 64, 300, 0.3), (2, 1, 1, 257, 0.3), (2, 2, 45, 1281, 1.0), (64, 8, 44, 1500, 0.3)])
+def test_attention_backward_few_queries_one_pass(ops, dev, Bn, H, Lq, Lk, scale):
+    """ns_attn_bwd with a workspace at <= 64 queries (the decoder's cross-attention: label length x 1500 encoder states) = attn_bwd_fewq_kernel:
+    K / V streamed once, dK / dV as in the two-pass kernel (bit-identical), dQ from the transposed recomputation through fp32 slabs (one per group
+    of key blocks) + a fixed-order reduction.  Against torch autograd in fp32 and against the two-pass kernels; ragged key counts (300, 257 = one key in
+    the last block of its group, 1281 = one key in a group of its own), one query, a full 64-query tile, and the bench size."""
+    d = H * 64
+    qx = rnd((Bn * Lq, d), dev, scale, seed=1)
+    kv = rnd((Bn * Lk, 2 * d), dev, 2 * scale, seed=2)
+    O = torch.zeros(Bn * Lq, d, device=dev, dtype=torch.float16)
+    LSE = torch.zeros(Bn, H, Lq, device=dev)
+    common = dict(Q=qx, K=kv, V=(kv, d), O=O, B=Bn, H=H, Lq=Lq, Lk=Lk, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, causal=False, LSE=LSE)
+    ops.attn_fwd(**common)
+    dO = rnd((Bn * Lq, d), dev, 0.5, seed=3)
+    nws = ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk)
+    assert nws % (Bn * H * Lq * 64 * 4) == 0 and nws > 0      # one fp32 dQ slab per group of key blocks
+    res = {}
+    for name, ws in (("two", None), ("one", torch.full((nws,), 0xFF, device=dev, dtype=torch.uint8))):   # slabs start as NaNs
+        dQ = torch.full((Bn * Lq, d), float("nan"), device=dev, dtype=torch.float16)
+        dKV = torch.full((Bn * Lk, 2 * d), float("nan"), device=dev, dtype=torch.float16)
+        Delta = torch.zeros(Bn, H, Lq, device=dev)
+        ops.attn_bwd(**common, dO=dO, dQ=dQ, dK=dKV, dV=(dKV, d), Delta=Delta, lddo=d, lddq=d, lddk=2 * d, lddv=2 * d, workspace=ws)
+        assert not torch.isnan(dQ.float()).any() and not torch.isnan(dKV.float()).any(), name
+        res[name] = (dQ.reshape(Bn, Lq, H, 64).float(), dKV[:, :d].reshape(Bn, Lk, H, 64).float(), dKV[:, d:].reshape(Bn, Lk, H, 64).float(), Delta.clone())
+    dq1, dk1, dv1, de1 = res["one"]
+    dq2, dk2, dv2, de2 = res["two"]
+    close(de1, de2, 1e-5, 1e-5, "delta")
+    # dK / dV: the same products in the same order as the two-pass kernel, from a delta summed in another order (last-bit differences in dS)
+    close(dk1, dk2, 2e-3 * max(dk2.std().item(), 1e-3), 4e-3, "dK one pass vs two passes")
+    close(dv1, dv2, 2e-3 * max(dv2.std().item(), 1e-3), 4e-3, "dV one pass vs two passes")
+    if Bn * H <= 16:     # autograd reference (the bench-size case compares the two kernel forms only)
+        q = qx.float().reshape(Bn, Lq, H, 64).requires_grad_(True)
+        k = kv[:, :d].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+        v = kv[:, d:].float().reshape(Bn, Lk, H, 64).requires_grad_(True)
+        ref, _ = attn_ref(q, k, v, False)
+        ref.backward(dO.float().reshape(Bn, Lq, H, 64))
+        close(dq1, q.grad, max(4e-3, 2e-2 * q.grad.std().item()), 2e-2, "dQ")
+        # whole-tensor relative error against autograd: no worse than the two-pass kernels (element-wise bounds on dK depend on how sharp the softmax is)
+        rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+        for nm, one, two, g in (("dQ", dq1, dq2, q.grad), ("dK", dk1, dk2, k.grad), ("dV", dv1, dv2, v.grad)):
+            e1, e2 = rel(one, g), rel(two, g)
+            print(f"  [{Lq}x{Lk} scale {scale}] {nm}: one-pass rel {e1:.2e}, two-pass rel {e2:.2e}")
+            assert e1 < 1.2 * e2 + 2e-4 and e1 < 2e-2, (nm, e1, e2)
+    else:
+        close(dq1, dq2, 2e-2 * dq2.std().item(), 2e-2, "dQ one pass vs two passes")
+    # bitwise reproducible: fixed-order slab sums, no atomics
+    dQb = torch.zeros(Bn * Lq, d, device=dev, dtype=torch.float16)
+    dKVb = torch.zeros(Bn * Lk, 2 * d, device=dev, dtype=torch.float16)
+    ops.attn_bwd(**common, dO=dO, dQ=dQb, dK=dKVb, dV=(dKVb, d), Delta=torch.zeros(Bn, H, Lq, device=dev), lddo=d, lddq=d, lddk=2 * d, lddv=2 * d,
+                 workspace=torch.zeros(nws, device=dev, dtype=torch.uint8))
+    assert torch.equal(dQb.reshape(Bn, Lq, H, 64).float(), dq1)
+
+
 @pytest.mark.parametrize("Bn,H,Lq,Lk,scale", [(2, 4, 1500, 1500, 0.3), (1, 2, 700, 700, 0.3), (1, 3, 256, 512, 0.3), (2, 2, 1500, 1500, 1.2),
                                                (1, 1, 320, 1281, 0.3)])
 def test_attention_backward_one_pass(ops, dev, Bn, H, Lq, Lk, scale):
@@ -427,7 +480,7 @@ def test_attention_backward_one_pass(ops, dev, Bn, H, Lq, Lk, scale):
     ref.backward(dO.float().reshape(Bn, Lq, H, 64))
     nws = ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk)
     assert nws == Bn * H * ((Lq + 63) // 64) * 64 * 64 * 4
-    assert ops.attn_bwd_workspace_bytes(Bn, H, 40, Lk) == 0 and ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk, causal=True) == 0
+    assert ops.attn_bwd_workspace_bytes(Bn, H, 100, Lk) == 0 and ops.attn_bwd_workspace_bytes(Bn, H, Lq, Lk, causal=True) == 0
     res = {}
     for name, ws in (("two", None), ("one", torch.full((nws,), 0xFF, device=dev, dtype=torch.uint8))):   # scratch starts as NaNs
         dQ = torch.zeros(Bn * Lq, 3 * d, device=dev, dtype=torch.float16)
