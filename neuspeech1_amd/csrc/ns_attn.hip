@@ -504,13 +504,14 @@ constexpr int FEWQ_KPW = NS_FEWQ_KPW;       // key blocks of 128 per workgroup (
 __device__ __forceinline__ int dst_off(int q, int chunk) { return q * 256 + ((chunk ^ (q & 15)) << 4); }   // [64 q][128 keys] fp16, conflict-free row reads
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_fewq_kernel(const ns_attn_desc p, float* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512 + 16384 + 16384];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512 + 3 * 16384];
   char* const Qs = smem;
   char* const dOs = smem + 8192;
   float* const lse_s = (float*)(smem + 16384);
   float* const del_s = lse_s + 64;
-  char* const Kimg = smem + 16384 + 512;
-  char* const dST = Kimg + 16384;
+  char* const Kimg = smem + 16384 + 512;     // [128 keys][64 d] of the current block (row reads: fragments; transposed reads: K^T for dQ)
+  char* const Vimg = Kimg + 16384;           // [128 keys][64 d]; each wave's 32 rows double as its dK / dV store staging
+  char* const dST = Vimg + 16384;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
   int bx_, h, b;
   xcd_block_ids(bx_, h, b);
@@ -551,25 +552,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fewq_kernel(const ns_attn_des
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
 
-  // this wave's key fragments, requested one key block ahead (the launch is a chain of load -> products -> store per block otherwise: two
-  // workgroups per CU do not cover a strided fetch from HBM)
-  half8 kf[4], vf[4], kfn[4], vfn[4];
-  auto load_kv = [&](int kb0, half8 (&kk)[4], half8 (&vv)[4]) __attribute__((always_inline)) {
-    const int krow = min(kb0 + wave * 32 + lr, p.Lk - 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kk[s] = *(const half8*)(K + (long long)krow * p.ldk + 16 * s + 8 * lh);
-      vv[s] = *(const half8*)(V + (long long)krow * p.ldv + 16 * s + 8 * lh);
-    }
-  };
-  load_kv(bx_ * FEWQ_KPW * 128, kfn, vfn);
+  // Global side of K / V / dK / dV: a wave's 32 key rows as four instructions of 8 rows x 128 B (lanes 0-3 | 8-11 one row's two halves,
+  // 4-7 | 12-15 the next row's: whole 128-B lines per instruction, and conflict-free 16-byte LDS stores -- see rm_lane).  Fragment loads
+  // straight into registers (lane = key row, 32 rows x 32 B per instruction) are bound by the CU's request rate, not by HBM: 3.0 TB/s.
+  const int l16 = lane & 15;
+  const int srow = 2 * (lane >> 4) + ((l16 >> 2) & 1), schunk = (l16 & 3) + 4 * (l16 >> 3);   // + 8 i rows for instruction i
+  // the next key block, requested one block ahead (two workgroups per CU do not cover an HBM fetch otherwise).  Named registers, not an array:
+  // hipcc keeps an array that a lambda fills inside this runtime loop in scratch memory
+  uint4 kn0, kn1, kn2, kn3, vn0, vn1, vn2, vn3;
+#define NS_FEWQ_LD(i, kr, vr)                                                              \
+  do {                                                                                     \
+    const int krow_ = min(kb_ + wave * 32 + 8 * (i) + srow, p.Lk - 1);                     \
+    kr = *(const uint4*)(K + (long long)krow_ * p.ldk + schunk * 8);                       \
+    vr = *(const uint4*)(V + (long long)krow_ * p.ldv + schunk * 8);                       \
+  } while (0)
+#define NS_FEWQ_LOAD_KV(kb)                                                                \
+  do {                                                                                     \
+    const int kb_ = (kb);                                                                  \
+    NS_FEWQ_LD(0, kn0, vn0); NS_FEWQ_LD(1, kn1, vn1); NS_FEWQ_LD(2, kn2, vn2); NS_FEWQ_LD(3, kn3, vn3); \
+  } while (0)
+#define NS_FEWQ_ST(i, kr, vr)                                                              \
+  do {                                                                                     \
+    *(uint4*)(Kimg + lds_off(wave * 32 + 8 * (i) + srow, schunk)) = kr;                    \
+    *(uint4*)(Vimg + lds_off(wave * 32 + 8 * (i) + srow, schunk)) = vr;                    \
+  } while (0)
+  NS_FEWQ_LOAD_KV(bx_ * FEWQ_KPW * 128);
   for (int kbi = 0; kbi < FEWQ_KPW; ++kbi) {
     const int kb0 = (bx_ * FEWQ_KPW + kbi) * 128;
     if (kb0 >= p.Lk) break;       // block-uniform
     const int key = kb0 + wave * 32 + lr;
+    NS_FEWQ_ST(0, kn0, vn0); NS_FEWQ_ST(1, kn1, vn1); NS_FEWQ_ST(2, kn2, vn2); NS_FEWQ_ST(3, kn3, vn3);
+    if (kbi + 1 < FEWQ_KPW && kb0 + 128 < p.Lk) NS_FEWQ_LOAD_KV(kb0 + 128);
+    half8 kf[4], vf[4];      // this wave's rows only: written and read by the same wave, in order
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = kfn[s]; vf[s] = vfn[s]; }
-    if (kbi + 1 < FEWQ_KPW && kb0 + 128 < p.Lk) load_kv(kb0 + 128, kfn, vfn);
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *(const half8*)(Kimg + lds_off(wave * 32 + lr, 2 * s + lh));
+      vf[s] = *(const half8*)(Vimg + lds_off(wave * 32 + lr, 2 * s + lh));
+    }
     // ---- dK^T, dV^T (query on the accumulator rows; the row constants ride in as the initial accumulators)
     {
       f32x16 dkt[2], dvt[2];
@@ -618,6 +637,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fewq_kernel(const ns_attn_des
             dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, dsb, dkt[dt], 0, 0, 0);
           }
         }
+      // dK, dV: a lane holds 64 d-values of ITS key; through the wave's own 32 rows of the V image (its V fragments are in registers) they
+      // leave as 128-B row segments
+#ifdef NS_FEWQ_DIRECT_STORE
       if (key < p.Lk) {
         half_t* dK = (half_t*)p.dK + ((long long)b * p.Lk + key) * p.lddk + h * D;
         half_t* dV = (half_t*)p.dV + ((long long)b * p.Lk + key) * p.lddv + h * D;
@@ -632,11 +654,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fewq_kernel(const ns_attn_des
             *(half4*)(dV + dt * 32 + 8 * g + 4 * lh) = ov_;
           }
       }
-    }
-    // ---- dS^T (key on the accumulator rows, query on the lane) -> [query][key] image; this wave's key rows -> [key][d] image
-    {
+#else
+      (void)key;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) *(half8*)(Kimg + lds_off(wave * 32 + lr, 2 * s + lh)) = kf[s];
+      for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(which ? dvt[dt][4 * g + e] : dkt[dt][4 * g + e]);
+            *(half4*)(Vimg + lds_off(wave * 32 + lr, 4 * dt + g) + 8 * lh) = o;
+          }
+        half_t* const dst = which ? (half_t*)p.dV + h * D : (half_t*)p.dK + h * D;
+        const long long ldd = which ? p.lddv : p.lddk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint4 v = *(const uint4*)(Vimg + lds_off(wave * 32 + 8 * i + srow, schunk));
+          const int krow = kb0 + wave * 32 + 8 * i + srow;
+          if (krow < p.Lk) *(uint4*)(dst + ((long long)b * p.Lk + krow) * ldd + schunk * 8) = v;
+        }
+      }
+#endif
+    }
+    // ---- dS^T (key on the accumulator rows, query on the lane) -> [query][key] image; the [key][d] image is the staged K block itself
+    {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         const float nl = lse_s[qt * 32 + lr], nd = del_s[qt * 32 + lr];
