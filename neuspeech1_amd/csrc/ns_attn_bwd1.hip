@@ -150,11 +150,15 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   const int krow = min(key, p.Lk - 1);
   const bool keyok = key < p.Lk;
   half8 kf[4], vf[4];
+#ifdef NS_AB1_DIRECT_LOAD
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     kf[s] = ns_ld<half8>(K, 2u * ((uint32_t)krow * p.ldk + 16 * s + 8 * lh));
     vf[s] = ns_ld<half8>(V, 2u * ((uint32_t)krow * p.ldv + 16 * s + 8 * lh));
   }
+#else
+  (void)krow;
+#endif
   // K^T fragments of the dQ product (B operand of 16x16x32: lane n = d column, 8 consecutive keys per k-group): the sweep's
   // K rows go through LDS once (coalesced 16-B loads into the second dS image, which no step has touched yet) and come
   // back transposed.  Keys past Lk (last sweep) enter as ZERO rows: whatever their dS holds, they add nothing to dQ.
@@ -179,23 +183,37 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   asm volatile("" : "+s"(q_first));
   {
     char* const KT = DS0 + KB * 128;
-    // every request of the sweep's prologue goes out before anything waits: the K rows for the image, then the first tile
-    uint4 kv[4];
+    // every request of the sweep's prologue goes out before anything waits: the K and V rows, then the first tile.  All as 128-B row
+    // segments (fragment loads straight into registers -- lane = key row, 32 rows x 32 B per instruction -- are bound by the CU's request
+    // rate): the rows go to LDS images and the fragments are read from there.  K twice: the plain image for the transposed reads of the
+    // K^T fragments (zero rows past Lk), and a swizzled one (first dS image, idle until step 0 writes it) for the row fragments; V into
+    // the two tile buffers (idle until the first tile is stored, one barrier later).
+    char* const KS = DS0;
+    char* const VS = smem;
+    uint4 kv[4], vv[4];
+    const int l16p = tid & 15;
+    const int prow = 2 * (tid >> 4) + ((l16p >> 2) & 1), pch = (l16p & 3) + 4 * (l16p >> 3);     // + 64 i rows (see rm_lane in ns_attn.hip)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int piece = tid + NT * i;             // 2048 pieces of 16 B: key = piece >> 3, chunk = piece & 7
-      const int kk = kb0 + (piece >> 3);
-      kv[i] = ns_ld<uint4>(K, 2u * ((uint32_t)min(kk, p.Lk - 1) * p.ldk + (piece & 7) * 8));
+      const uint32_t kk = (uint32_t)min(kb0 + 64 * i + prow, p.Lk - 1);
+      kv[i] = ns_ld<uint4>(K, 2u * (kk * p.ldk + pch * 8));
+#ifndef NS_AB1_DIRECT_LOAD
+      vv[i] = ns_ld<uint4>(V, 2u * (kk * p.ldv + pch * 8));
+#endif
     }
     load_tile(q_first);
     __syncthreads();            // the previous sweep's last reads of the images and tile buffers are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int piece = tid + NT * i;
-      const bool ok = kb0 + (piece >> 3) < p.Lk;
+      const int row = 64 * i + prow;
+      const bool ok = kb0 + row < p.Lk;
       uint4 v = kv[i];
+#ifndef NS_AB1_DIRECT_LOAD
+      *(uint4*)(KS + 8192 * i + lds_off(prow, pch)) = v;
+      *(uint4*)(VS + 8192 * i + lds_off(prow, pch)) = vv[i];
+#endif
       v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-      *(uint4*)(KT + piece * 16) = v;
+      *(uint4*)(KT + (row * 8 + pch) * 16) = v;
     }
     __syncthreads();
 #pragma unroll
@@ -206,6 +224,17 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
       const short8v a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       ktf[ks] = __builtin_bit_cast(half8, a);
     }
+#ifndef NS_AB1_DIRECT_LOAD
+    {
+      const int fr = wave * 32 + lr;        // this lane's key row of the sweep
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[s] = *(const half8*)(KS + 8192 * (fr >> 6) + lds_off(fr & 63, 2 * s + lh));
+        vf[s] = *(const half8*)(VS + 8192 * (fr >> 6) + lds_off(fr & 63, 2 * s + lh));
+      }
+    }
+    __syncthreads();            // the V image lies in the tile buffers: every wave has its fragments before the first tile is stored
+#endif
   }
   f32x16 dkt[2], dvt[2];
 #pragma unroll
@@ -374,6 +403,10 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   for (int t = 1; t < nsteps; ++t) step(T_{}, T_{}, t);
   step(T_{}, F_{}, t_last);
 
+  // dK, dV of the sweep's 256 keys: a lane holds 64 d-values of ITS key; written straight from there they are 8-byte pieces (16 B contiguous
+  // per row and instruction), and the CU retires such pieces at its request rate, not at HBM's -- the next sweep's loads queue behind them
+  // (one in-order vmcnt).  Through the wave's own 32 rows of the (now idle) tile buffers they leave as 128-B row segments.
+#ifdef NS_AB1_DIRECT_STORE
   if (keyok) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -386,6 +419,35 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
         ns_st<half4>(dV, 2u * ((uint32_t)key * p.lddv + dt * 32 + 8 * g + 4 * lh), ov_);
       }
   }
+#else
+  (void)keyok;
+  __syncthreads();            // every wave is through its last step: tile buffers and images are idle
+  {
+    char* const stg = smem + wave * 4096;          // 32 rows x 128 B of this wave, lds_off layout (8 waves: the two tile buffers)
+    const int l16 = lane & 15;
+    const int srow2 = 2 * (lane >> 4) + ((l16 >> 2) & 1), schunk2 = (l16 & 3) + 4 * (l16 >> 3);    // + 8 i rows: see rm_lane in ns_attn.hip
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(which ? dvt[dt][4 * g + e] : dkt[dt][4 * g + e]);
+          *(half4*)(stg + lds_off(lr, 4 * dt + g) + 8 * lh) = o;
+        }
+      half_t* const dst = which ? dV : dK;
+      const uint32_t ldd = (uint32_t)(which ? p.lddv : p.lddk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 v = *(const uint4*)(stg + lds_off(8 * i + srow2, schunk2));
+        const int krow2 = kb0 + wave * 32 + 8 * i + srow2;
+        if (krow2 < p.Lk) ns_st<uint4>(dst, 2u * ((uint32_t)krow2 * ldd + schunk2 * 8), v);
+      }
+    }
+  }
+#endif
 }
 
 __device__ __forceinline__ size_t ns_attn_bwd_workspace_bytes_dev(const ns_attn_desc& p) {
