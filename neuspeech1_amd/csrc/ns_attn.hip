@@ -60,11 +60,15 @@ __device__ __forceinline__ void rm_lane(int id, int& row, int& chunk) {
   row = 2 * (id >> 4) + ((l16 >> 2) & 1);
   chunk = (l16 & 3) + 4 * (l16 >> 3);
 }
+// (wave-uniform base + 32-bit byte offset of the lane, recomputed per tile: 64-bit per-lane address pairs are loop invariants that hipcc keeps live
+// through the tile loop -- or spills, each reload behind its own s_waitcnt vmcnt(0); a (batch, head)'s rows stay far below 4 GiB from its base)
 __device__ __forceinline__ void load_rm(const half_t* __restrict__ base, long long ld, int row0, int L, uint4& r0, uint4& r1) {
   int row, chunk;
   rm_lane(threadIdx.x, row, chunk);
-  r0 = *(const uint4*)(base + (long long)min(row0 + row, L - 1) * ld + chunk * 8);
-  r1 = *(const uint4*)(base + (long long)min(row0 + 32 + row, L - 1) * ld + chunk * 8);
+  const uint32_t o0 = 2u * ((uint32_t)min(row0 + row, L - 1) * (uint32_t)ld + (uint32_t)chunk * 8u);
+  const uint32_t o1 = 2u * ((uint32_t)min(row0 + 32 + row, L - 1) * (uint32_t)ld + (uint32_t)chunk * 8u);
+  r0 = *(const uint4*)((const char*)base + o0);
+  r1 = *(const uint4*)((const char*)base + o1);
 }
 __device__ __forceinline__ void store_rm(char* lds, const uint4& r0, const uint4& r1) {
   int row, chunk;
@@ -113,9 +117,23 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
   const int qrow = min(qi, p.Lq - 1);
   const int coff = p.Lk - p.Lq;                   // causal: key j visible iff j <= qi + coff
 
+  // Global rows as 128-B segments through LDS, never as per-lane fragment pieces (lane = row: 32 rows x 32 B per load instruction, 16 B per
+  // row and store instruction -- the CU retires such pieces at its request rate, well below HBM's): this wave's 32 query rows go through
+  // its own 4 KiB of the (still idle) K / V tile buffers, and O leaves the same way.
   half8 qf[4];
+  (void)qrow;
+  {
+    const int l16 = lane & 15;
+    const int srow = 2 * (lane >> 4) + ((l16 >> 2) & 1), schunk = (l16 & 3) + 4 * (l16 >> 3);   // + 8 i rows: see rm_lane
+    char* const wst = smem + wave * 4096;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(Q + (long long)qrow * p.ldq + 16 * s + 8 * lh);
+    for (int i = 0; i < 4; ++i) {
+      const int qr = min(q0 + wave * 32 + 8 * i + srow, p.Lq - 1);
+      *(uint4*)(wst + lds_off(8 * i + srow, schunk)) = *(const uint4*)(Q + (long long)qr * p.ldq + schunk * 8);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(wst + lds_off(lr, 2 * s + lh));
+  }
 
   f32x16 ot[2];
 #pragma unroll
@@ -210,19 +228,30 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (qi < p.Lq) {
-    half_t* O = (half_t*)p.O + ((long long)b * p.Lq + qi) * p.ldo + h * D;
+  __syncthreads();      // every wave is through the last tile: the tile buffers are idle
+  // (lane-derived staging offsets are re-derived here from a laundered thread index: kept live through the tile loop they cost the
+  // registers that hold this kernel at four waves per SIMD)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, l16 = lane_e & 15, lr_e = lane_e & 31, lh_e = lane_e >> 5;
+  const int srow = 2 * (lane_e >> 4) + ((l16 >> 2) & 1), schunk = (l16 & 3) + 4 * (l16 >> 3);
+  char* const wst = smem + (tid_e >> 6) * 4096;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        half4 o;
+    for (int g = 0; g < 4; ++g) {
+      half4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][4 * g + e] * inv);
-        *(half4*)(O + dt * 32 + 8 * g + 4 * lh) = o;
-      }
-    if (p.LSE && lh == 0) p.LSE[((long long)b * p.H + h) * p.Lq + qi] = m_run + __logf(l_tot);
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][4 * g + e] * inv);
+      *(half4*)(wst + lds_off(lr_e, 4 * dt + g) + 8 * lh_e) = o;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint4 v = *(const uint4*)(wst + lds_off(8 * i + srow, schunk));
+    const int qr = q0 + wave * 32 + 8 * i + srow;
+    if (qr < p.Lq) *(uint4*)((half_t*)p.O + ((long long)b * p.Lq + qr) * p.ldo + h * D + schunk * 8) = v;
   }
+  if (qi < p.Lq && p.LSE && lh == 0) p.LSE[((long long)b * p.H + h) * p.Lq + qi] = m_run + __logf(l_tot);
 }
 
 // =============================================================== backward: dQ (+ delta)
