@@ -6,7 +6,8 @@
 //     that start at ring buffer 1, so ring buffer 0 is free from the moment the main loop ends: the four regions of the NEXT
 //     tile's first K tile (8 DMA pieces per wave) and its 256 bias values (a ninth piece, into a 1-KiB LDS slot) are requested
 //     between the conversions of the first half and land under the stores.  The remaining two regions (K tile 1 -> buffer 1)
-//     and the second product's fragments follow the last store.
+//     follow the last store, and with them the second product's first round: the tile's 256 x 32 slices of A2 / B2 as LDS-DMA pieces
+//     into ring buffer 1's two idle regions (stage_k2; fragment loads straight into registers cost 18 % of a K = 512 tile).
 //   * A tile's set-up, its prologue latency (6.1 k of 41 k cycles in the one-tile form at K = 512) and the workgroup launch are paid
 //     once per CU; what the half-wise epilogue costs more than the whole-tile one (two more barriers, 4.8 k + 5.9 k against 3.0 k +
 //     5.9 k cycles) takes most of it back: 36-37 k cycles per K = 512 tile against 41 k, 0-8 % per launch on the step's shapes.
@@ -63,7 +64,7 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, const T& v) 
 #define NS_STAMP(i) do { } while (0)
 #endif
 
-template <bool DROP, int KIND>
+template <bool DROP, int KIND, bool K2LDS>
 __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_in) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,6 +110,33 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
   uint32_t a_src[2][2], b_src[2][2];
   int my_chunk[2];
   int src_n0 = 0;
+  // Second (LoRA) product, first 32-deep round (K2LDS instantiations: K2 > 0 and one column group per tile, a2_ngroup % 256 == 0): the tile's
+  // 256 x 32 slices of A2 and B2 (64-B rows) come in as 1-KiB LDS-DMA pieces, like every other operand, into the two regions of ring buffer 1
+  // that are idle until phase 1 / 2 of the main loop refill them (RA1 <- A2 rows, RB1 <- B2 rows).  Fragment loads straight into registers
+  // (16 rows x 64 B per instruction) are bound by the CU's request rate: 1 536 pieces per tile took 7.5 k cycles, 18 % of a K = 512 tile for
+  // 6 % of its FLOPs.  16-B chunk c of image row r sits at chunk c ^ ((r >> 2) & 2): conflict-free ds_read_b128 fragment reads at a 64-B row
+  // stride.  (A template parameter, not a run-time flag: with the code merely present, hipcc's allocation of the OTHER launches' epilogues
+  // shifted and they lost 2-5 % in a same-box A/B of the two builds.)
+  const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(K2LDS ? p.A2 : p.A), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b2 = __builtin_amdgcn_make_buffer_rsrc((void*)(K2LDS ? p.B2 : p.B), 0, 0x80000000u, 0x00020000);
+  auto stage_k2 = [&](int wtile, int lane) __attribute__((always_inline)) {
+    ns_rowmap am2 = p.am2;
+    int tn_div = tiles_n, a2g = p.a2_ngroup;
+    asm volatile("" : "+s"(am2.seg_rows), "+s"(tn_div), "+s"(a2g));
+    const int tm_ = wtile / tn_div;
+    const int m0 = tm_ * BM, n0 = (wtile - tm_ * tn_div) * BN;
+    const uint32_t goff = a2g > 0 ? (uint32_t)((n0 / a2g) * p.K2) : 0u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * (2 * wave + j) + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 2);
+      const bool ok = c * 8 < p.K2;
+      const uint32_t ao = 2u * (rm_off32(am2, min(m0 + row, p.M - 1)) + goff + (uint32_t)c * 8u);
+      const uint32_t bo = 2u * ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldb2 + (uint32_t)c * 8u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (lds_void*)(smem + BUF + RA1 * REGION + (2 * wave + j) * 1024), 16, ok ? ao : 0x80000000u, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b2, (lds_void*)(smem + BUF + RB1 * REGION + (2 * wave + j) * 1024), 16, ok ? bo : 0x80000000u, 0, 0, 0);
+    }
+  };
   auto set_src = [&](int wtile, int lane) __attribute__((always_inline)) {
     // divisors laundered: their reciprocals are formed here, per tile, not above the tile loop (where they would be spilled)
     ns_rowmap am = p.am;
@@ -218,6 +246,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
   set_src(xstart + ti, lane);
   stage_bias(src_n0, 0, lane);
   stage(0, RA0, 0); stage(0, RB0, 0); stage(0, RB1, 0); stage(0, RA1, 0);
+  if (K2LDS) stage_k2(xstart + ti, lane);
   stage(1, RA0, 1); stage(1, RB0, 1);
   int par = 0;    // bias slot of the current tile
 
@@ -243,8 +272,8 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- second product (LoRA up-projection, K2 = 16 .. 96): fragments straight from global memory, requested BEHIND the
-    // DMA pieces in flight (their wait therefore also covers the prologue, which phase 1 needs anyway)
+    // ---- second product (LoRA up-projection, K2 = 16 .. 96): the first 32-deep round from the LDS images (stage_k2), further rounds
+    // (the stacked q|k|v bottleneck of a dgrad, 3r) and column groups narrower than a tile as fragments straight from global memory
     if (p.K2 > 0) {
       half8 a2f[2][4], b2f[2][2];
       uint32_t a2o[2][4], b2o[2][2];     // byte offsets from A2 / B2 (< 2^32: ns_gemm_p8s_ok)
@@ -264,7 +293,38 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           const int col = min(n0 + wn * 64 + bh * 32 + nt * 16 + l15, p.N - 1);
           b2o[bh][nt] = 2u * ((uint32_t)col * (uint32_t)p.ldb2);
         }
-      for (int k0 = 0; k0 < p.K2; k0 += 32) {
+      if (K2LDS) {
+        // round 0 from the LDS images: the four K2 pieces of this wave are older than the four pieces of K tile 1 behind them
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        NS_P8_BARRIER();
+        const char* const a2img = smem + BUF + RA1 * REGION;
+        const char* const b2img = smem + BUF + RB1 * REGION;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int row = wm * 128 + ah * 64 + mt * 16 + l15;
+            a2f[ah][mt] = *(const half8*)(a2img + row * 64 + ((lg ^ ((row >> 2) & 2)) << 4));
+          }
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int row = wn * 64 + bh * 32 + nt * 16 + l15;
+            b2f[bh][nt] = *(const half8*)(b2img + row * 64 + ((lg ^ ((row >> 2) & 2)) << 4));
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[ah][mt][bh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2f[bh][nt], a2f[ah][mt], acc[ah][mt][bh][nt], 0, 0, 0);
+      }
+      for (int k0 = K2LDS ? 32 : 0; k0 < p.K2; k0 += 32) {
         const bool ok = k0 + 8 * lg < p.K2;
         const int ko = ok ? k0 + 8 * lg : 0;
 #pragma unroll
@@ -534,18 +594,24 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     if (!has_next) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     NS_P8_BARRIER();          // every wave is done with the staged half: ring buffer 1 may be refilled
+    if (K2LDS) stage_k2(xstart + tnext, lane_e);
     stage(1, RA0, 1); stage(1, RB0, 1);
     ti = tnext;
     par ^= 1;
   }
 }
 
-template <bool DROP>
+template <bool DROP, bool K2LDS>
 void launch_kind(const ns_gemm_desc* d, int grid, hipStream_t st) {
   const int kind = d->H32 ? NS_EPI_RES : ((d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) ? NS_EPI_DGELU : NS_EPI_PLAIN);
-  if (kind == NS_EPI_RES) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_RES>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
-  else if (kind == NS_EPI_DGELU) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_DGELU>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
-  else hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  if (kind == NS_EPI_RES) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_RES, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else if (kind == NS_EPI_DGELU) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_DGELU, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+}
+
+template <bool DROP, int KIND, bool K2LDS>
+void set_lds_attr() {
+  hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<DROP, KIND, K2LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 }
 
 }  // namespace
@@ -571,19 +637,18 @@ int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st) {
   static std::once_flag attr_once;   // lazily created immutable kernel attributes: std::call_once (include/neuspeech_hip.h, threading)
   static int cus_per_xcd = 32;
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<false, NS_EPI_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<true, NS_EPI_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    set_lds_attr<false, NS_EPI_PLAIN, false>(); set_lds_attr<false, NS_EPI_RES, false>(); set_lds_attr<false, NS_EPI_DGELU, false>();
+    set_lds_attr<true, NS_EPI_PLAIN, false>(); set_lds_attr<true, NS_EPI_RES, false>(); set_lds_attr<true, NS_EPI_DGELU, false>();
+    set_lds_attr<false, NS_EPI_PLAIN, true>(); set_lds_attr<false, NS_EPI_RES, true>(); set_lds_attr<false, NS_EPI_DGELU, true>();
+    set_lds_attr<true, NS_EPI_PLAIN, true>(); set_lds_attr<true, NS_EPI_RES, true>(); set_lds_attr<true, NS_EPI_DGELU, true>();
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
       cus_per_xcd = cus / 8;
   });
   // one workgroup per CU (148 KiB of LDS, 512 threads x 256 registers: nothing else fits beside it), 8 XCDs round-robin
   const int per_xcd = std::min(cus_per_xcd, (tiles + 7) / 8);
-  if (d->drop_p > 0.f) launch_kind<true>(d, 8 * per_xcd, st);
-  else launch_kind<false>(d, 8 * per_xcd, st);
+  const bool k2lds = d->K2 > 0 && (d->a2_ngroup == 0 || d->a2_ngroup % BN == 0);   // one column group per tile: the LDS form of the second product
+  if (d->drop_p > 0.f) { if (k2lds) launch_kind<true, true>(d, 8 * per_xcd, st); else launch_kind<true, false>(d, 8 * per_xcd, st); }
+  else { if (k2lds) launch_kind<false, true>(d, 8 * per_xcd, st); else launch_kind<false, false>(d, 8 * per_xcd, st); }
   return 0;
 }

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneuspeech_hip.so")
+LIB_PATH = os.environ.get("NS_LIB_PATH") or os.path.join(_HERE, "libneuspeech_hip.so")   # NS_LIB_PATH: same-box A/B of two builds (probes only)
 
 
 class NeuSpeechHipError(RuntimeError):

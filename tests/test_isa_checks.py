@@ -51,7 +51,7 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-@pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 6)])
+@pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 12)])
 def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, kernel, count):
     kernels = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
     assert len(kernels) == count, list(kernels)
@@ -115,7 +115,7 @@ def test_persistent_gemm_k_loop_has_no_scratch(tmp_path):
     reloaded before the next one); the K loop itself -- the depth-2 loop that holds the 128 main-product MFMAs, with its hand-counted
     vmcnt(8) waits -- must not touch scratch in any variant, and must not wait for an empty vector-memory queue."""
     ks = {k: v for k, v in _kernels(_asm("ns_gemm_p8s.hip", tmp_path)).items() if "ns_gemm_p8s_kernel" in k}
-    assert len(ks) == 6
+    assert len(ks) == 12
     for name, body in ks.items():
         text = "\n".join(body)
         loops = [m.start() for m in re.finditer(r"Inner Loop Header: Depth=2", text)]
@@ -131,3 +131,10 @@ def test_persistent_gemm_k_loop_has_no_scratch(tmp_path):
             assert "vmcnt(0)" not in loop, name
             assert len(re.findall(r"s_barrier", loop)) == 16, name     # two K tiles x four phases x two barriers
         assert found, f"{name}: K loop not found"
+        # the plain and the gelu'-multiply epilogues must not spill at all (a reload between their stores waits for every store before it; a guard
+        # around the second product's address set-up once cost these variants 25-45 registers and 7-12 % of their launches)
+        n_scr = len(re.findall(r"scratch_(load|store)", text))
+        if "ELi1E" in name:
+            assert n_scr <= 48, (name, n_scr)          # residual epilogue: the next tile's addresses are parked across the epilogue
+        else:
+            assert n_scr == 0, (name, n_scr)

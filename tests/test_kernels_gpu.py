@@ -925,7 +925,7 @@ def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
 
 
 def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
-    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 512 tiles) against ns_gemm_p8 (one tile per
+    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 256 tiles) against ns_gemm_p8 (one tile per
     workgroup) on ragged shapes with > 256 tiles, so that workgroups really carry the next tile's prologue through an epilogue:
     every epilogue kind, second product (ragged column groups, LoRA dropout), segmented row maps with an in-place residual, the
     GELU side product.  Same arithmetic in the same order: outputs must be bit-identical."""
@@ -965,6 +965,15 @@ def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
         E = nan16(N)
         ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(2 * r), K2=16, B2=Bs, ldb2=r, a2_ngroup=384, C16=E, c16m=ops.rowmap(N))
         out["second_k2_16"] = (E,)
+        # the persistent form fetches the second product's first round through LDS when a tile lies in ONE column group (a2_ngroup % 256 == 0):
+        # two groups of 512 columns (the second ragged), K2 = 32; no groups, K2 = 16 (half of each 64-B image row comes from the range check)
+        E2 = nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(2 * r), K2=r, B2=Bs, ldb2=r, a2_ngroup=512, bias=bias,
+                 C16=E2, c16m=ops.rowmap(N), drop_p=0.05, drop_seed=9)
+        out["second_groups_512"] = (E2,)
+        E3 = nan16(N)
+        ops.gemm(A=A, am=ops.rowmap(K), K=K, B=B, ldb=K, M=M, N=N, A2=u, am2=ops.rowmap(2 * r), K2=16, B2=Bs, ldb2=r, C16=E3, c16m=ops.rowmap(N))
+        out["second_k2_16_one_group"] = (E3,)
         Hc = Rc.clone()
         ops.gemm(A=(img, 0), am=ops.rowmap(2 * Cin, T2, (2 * T2 + 2) * Cin), K=3 * Cin, B=Wc, ldb=3 * Cin, M=segs * T2, N=N,
                  bias=bias, R32=Hc, H32=Hc, h32m=ops.rowmap(N))
@@ -993,3 +1002,5 @@ def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
     sec[:, :384] += u[:, :16].float() @ Bs[:384, :16].float().T
     sec[:, 384:] += u[:, 16:32].float() @ Bs[384:, :16].float().T      # group g reads columns [g K2, (g + 1) K2) of A2
     close(ref["second_k2_16"][0], sec, 6e-3, 3e-3, "second product, K2 = 16")
+    sec1 = A.float() @ B.float().T + u[:, :16].float() @ Bs[:, :16].float().T
+    close(got["second_k2_16_one_group"][0], sec1, 6e-3, 3e-3, "second product through LDS, K2 = 16")

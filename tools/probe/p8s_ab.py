@@ -1,4 +1,4 @@
-"""Persistent phase-interleaved GEMM (mode 9) against the one-tile-per-workgroup kernel (mode 1): outputs bit-compared, then timed
+"""Persistent phase-interleaved GEMM (mode 9) against the one-tile-per-workgroup kernel (mode 4): outputs bit-compared, then timed
 (same process, modes alternated per repeat).  Shapes = the training step's large-M GEMMs."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -47,17 +47,17 @@ only = os.environ.get("ONLY")
 for name in ca:
     if only and only not in name: continue
     fa, flops, keys = ca[name]; fb = cb[name][0]
-    L.ns_debug_set_ring(1); fa(); torch.cuda.synchronize()
+    L.ns_debug_set_ring(4); fa(); torch.cuda.synchronize()
     L.ns_debug_set_ring(9); fb(); torch.cuda.synchronize()
     bad = {k: int((oa[k] != ob[k]).sum().item()) for k in keys}
     nan = {k: bool(torch.isnan(ob[k].float()).any().item()) for k in keys}
-    best = {1: 1e9, 9: 1e9}
+    best = {4: 1e9, 9: 1e9}
     if not os.environ.get("NOTIME"):
         for rep in range(4):
-            for m, fn in ((1, fa), (9, fb)):
+            for m, fn in ((4, fa), (9, fb)):
                 L.ns_debug_set_ring(m)
                 best[m] = min(best[m], t(fn))
     if name == "dgrad qkv+lora":   # o3 is an input there: keep both copies equal
         pass
-    print(f"{name:22s} mismatches {bad} nan {nan}   mode1 {best[1]*1000:7.1f} us {flops/best[1]/1e9:6.0f} TF/s   mode9 {best[9]*1000:7.1f} us {flops/best[9]/1e9:6.0f} TF/s", flush=True)
+    print(f"{name:22s} mismatches {bad} nan {nan}   one-tile {best[4]*1000:7.1f} us {flops/best[4]/1e9:6.0f} TF/s   persistent {best[9]*1000:7.1f} us {flops/best[9]/1e9:6.0f} TF/s", flush=True)
 L.ns_debug_set_ring(1)
