@@ -27,9 +27,10 @@ GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
 # fwd+bwd" is measured on
 ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
-# the dominant kernel: the persistent phase-interleaved GEMM (its six instantiations) together with the one-tile-per-workgroup form it
-# falls back to (position-row epilogue, < 512 tiles) -- one arithmetic, one "nt256" class in the event-timed leg and in the rocprof rows
-DOMINANT = "ns_gemm_p8s_kernel"
+# the dominant kernel: the phase-interleaved 256 x 256 GEMM in its two forms -- one tile per workgroup (ns_gemm_p8_kernel: launches of < 1024
+# tiles, the position-row epilogue) and persistent (ns_gemm_p8s_kernel: >= 1024 tiles) -- one tile arithmetic, one "nt256" class in the
+# event-timed leg; in the rocprof stats its average launch = all ns_gemm_p8*_kernel rows together
+DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
 PMC_FILE = "profiles/r3_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 
 

@@ -48,7 +48,7 @@ def main():
     dom = [v for k, v in out["kernels"].items() if "ns_gemm_p8s_kernel" in k or "ns_gemm_p8_kernel" in k]   # persistent form + its one-tile fallback
     if dom:
         n = sum(v["launches"] for v in dom)
-        out["kernel"] = "ns_gemm_p8s_kernel"
+        out["kernel"] = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
         out["launches"] = n
         out["hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in dom) / n
     path = os.path.join(OUT, f"pmc_{tag}_traffic.json")
