@@ -365,6 +365,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
   const int ecol = n0 + ecg * 8;
   const bool ecolok = ecol + 8 <= p.N;
   const int ecolc = min(ecol, p.N - 8);
+  // residual epilogue: a thread owns columns {4 ecg .. +3} and {128 + 4 ecg .. +3} of its rows instead of 8 consecutive ones, so that the
+  // fp32 accesses of a wave instruction are 16 B per lane at 16-B pitch (512 contiguous bytes per row) and not every other 16-B chunk
+  const int rcolA = n0 + ecg * 4, rcolB = rcolA + 128;
+  const bool rokA = rcolA + 4 <= p.N, rokB = rcolB + 4 <= p.N;
+  const int rcolAc = min(rcolA, p.N - 4), rcolBc = min(rcolB, p.N - 4);
   auto stage_tile = [&]() __attribute__((always_inline)) {
     float4 bz[2][2];
 #pragma unroll
@@ -406,9 +411,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
       for (int i = i0; i < i0 + 8; ++i) {
         const int row = min(m0 + er0 + 16 * i, p.M - 1);
         if (KIND == NS_EPI_RES) {
-          const long long oh = ns_rm_off64(p.h32m, row) + ecolc;
-          res[i][0] = p.R32 ? *(const f32x4*)(p.R32 + oh) : f32x4{0.f, 0.f, 0.f, 0.f};
-          res[i][1] = p.R32 ? *(const f32x4*)(p.R32 + oh + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const long long oh = ns_rm_off64(p.h32m, row);
+          res[i][0] = p.R32 ? *(const f32x4*)(p.R32 + oh + rcolAc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          res[i][1] = p.R32 ? *(const f32x4*)(p.R32 + oh + rcolBc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (KIND == NS_EPI_DGELU) pre[i] = *(const half8*)(P16 + ns_rm_off64(p.p16m, row) + ecolc);
       }
@@ -416,9 +421,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 #pragma unroll
         for (int i = i0; i < i0 + 8; ++i) {
           const int row = min(m0 + er0 + 16 * i, p.M - 1);
-          const float* ps = p.pos + (long long)(row % p.pos_rows) * p.N + ecolc;
-          res[i][0] += *(const f32x4*)ps;
-          res[i][1] += *(const f32x4*)(ps + 4);
+          const float* ps = p.pos + (long long)(row % p.pos_rows) * p.N;
+          res[i][0] += *(const f32x4*)(ps + rcolAc);
+          res[i][1] += *(const f32x4*)(ps + rcolBc);
         }
       }
     };
@@ -448,12 +453,18 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
 #pragma unroll
     for (int i = 0; i < (KIND == NS_EPI_DGELU ? 16 : 0); ++i) asm volatile("" : "+v"(pre[i]));
     NS_STAMP(5);
-    if (ecolok) {
+    if (KIND == NS_EPI_RES ? rokA : ecolok) {      // (N % 8 == 0 and tiles start at multiples of 256: group A valid whenever anything of the thread is)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rl = er0 + 16 * i, row = m0 + rl;
         if (row >= p.M) continue;
-        half8 v = *(const half8*)(hs + rl * LDH + ecg * 16);
+        half8 v;
+        if (KIND == NS_EPI_RES) {
+          const half4 va = *(const half4*)(hs + rl * LDH + ecg * 8), vb = *(const half4*)(hs + rl * LDH + 256 + ecg * 8);
+          v = half8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        } else {
+          v = *(const half8*)(hs + rl * LDH + ecg * 16);
+        }
         if (KIND == NS_EPI_DGELU) {
           if (mulp) {
 #pragma unroll
@@ -473,8 +484,21 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
             if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
           }
         }
-        if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = cv;
-        if (G16) *(half8*)(G16 + ns_rm_off64(p.g16m, row) + ecol) = gv;
+        if (KIND == NS_EPI_RES) {
+          if (C16) {
+            half_t* const c = C16 + ns_rm_off64(p.c16m, row);
+            *(half4*)(c + rcolA) = half4{cv[0], cv[1], cv[2], cv[3]};
+            if (rokB) *(half4*)(c + rcolB) = half4{cv[4], cv[5], cv[6], cv[7]};
+          }
+          if (G16) {
+            half_t* const g = G16 + ns_rm_off64(p.g16m, row);
+            *(half4*)(g + rcolA) = half4{gv[0], gv[1], gv[2], gv[3]};
+            if (rokB) *(half4*)(g + rcolB) = half4{gv[4], gv[5], gv[6], gv[7]};
+          }
+        } else {
+          if (C16) *(half8*)(C16 + ns_rm_off64(p.c16m, row) + ecol) = cv;
+          if (G16) *(half8*)(G16 + ns_rm_off64(p.g16m, row) + ecol) = gv;
+        }
         if (KIND == NS_EPI_PLAIN && p.side_B) {
           // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged tile,
           // LoRA-dropout mask applied, for the MFMA pass below
@@ -491,9 +515,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8_kernel(const ns_gemm_desc p_in
           f32x4 h0 = res[i][0], h1 = res[i][1];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { h0[e] += (float)gv[e]; h1[e] += (float)gv[4 + e]; }
-          float* const hp = p.H32 + ns_rm_off64(p.h32m, row) + ecol;
-          *(f32x4*)hp = h0;
-          *(f32x4*)(hp + 4) = h1;
+          float* const hp = p.H32 + ns_rm_off64(p.h32m, row);
+          *(f32x4*)(hp + rcolA) = h0;
+          if (rokB) *(f32x4*)(hp + rcolB) = h1;
         }
       }
     }
