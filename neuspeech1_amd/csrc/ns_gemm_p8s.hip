@@ -404,6 +404,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     const int ecol = n0 + ecg * 8;
     const bool ecolok = ecol + 8 <= p.N;
     const int ecolc = min(ecol, p.N - 8);
+    // residual epilogue: a thread owns columns {4 ecg .. +3} and {128 + 4 ecg .. +3} of its rows instead of 8 consecutive ones: the fp32
+    // accesses of a wave instruction are then 16 B per lane at 16-B pitch (512 contiguous bytes per row), not every other 16-B chunk
+    const int rcolA = n0 + ecg * 4, rcolB = rcolA + 128;
+    const bool rokA = rcolA + 4 <= p.N, rokB = rcolB + 4 <= p.N;
+    const int rcolAc = min(rcolA, p.N - 4), rcolBc = min(rcolB, p.N - 4);
     half_t* const C16 = (half_t*)p.C16;
     half_t* const G16 = (half_t*)p.G16;
     const half_t* const P16 = (const half_t*)p.P16;
@@ -427,9 +432,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
       for (int i = 0; i < 8; ++i) {
         const int row = min(grow(hh, er0 + 16 * i), p.M - 1);
         if (KIND == NS_EPI_RES) {
-          const uint32_t oh = 4u * (rm_off32(h32m, row) + (uint32_t)ecolc);
-          res[i][0] = p.R32 ? ld32<f32x4>(p.R32, oh) : f32x4{0.f, 0.f, 0.f, 0.f};
-          res[i][1] = p.R32 ? ld32<f32x4>(p.R32, oh + 16u) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const uint32_t oh = rm_off32(h32m, row);
+          res[i][0] = p.R32 ? ld32<f32x4>(p.R32, 4u * (oh + (uint32_t)rcolAc)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          res[i][1] = p.R32 ? ld32<f32x4>(p.R32, 4u * (oh + (uint32_t)rcolBc)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (KIND == NS_EPI_DGELU) pre[hh * 8 + i] = ld32<half8>(P16, 2u * (rm_off32(p16m, row) + (uint32_t)ecolc));
       }
@@ -460,12 +465,19 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
       // this thread's 8 staged rows first (one LDS round trip, not eight)
       half8 vst[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vst[i] = *(const half8*)(hs + (er0 + 16 * i) * LDH + ecg * 16);
+      for (int i = 0; i < 8; ++i) {
+        if (KIND == NS_EPI_RES) {
+          const half4 va = *(const half4*)(hs + (er0 + 16 * i) * LDH + ecg * 8), vb = *(const half4*)(hs + (er0 + 16 * i) * LDH + 256 + ecg * 8);
+          vst[i] = half8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        } else {
+          vst[i] = *(const half8*)(hs + (er0 + 16 * i) * LDH + ecg * 16);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         {
           const int rl = er0 + 16 * i, row = grow(hh, rl);
-          if (!ecolok || row >= p.M) continue;
+          if (!(KIND == NS_EPI_RES ? rokA : ecolok) || row >= p.M) continue;
           half8 v = vst[i];
           if (KIND == NS_EPI_DGELU) {
             if (mulp) {
@@ -486,8 +498,21 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
               if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
             }
           }
-          if (C16) st32<half8>(C16, 2u * (rm_off32(c16m, row) + (uint32_t)ecol), cv);
-          if (G16) st32<half8>(G16, 2u * (rm_off32(g16m, row) + (uint32_t)ecol), gv);
+          if (KIND == NS_EPI_RES) {
+            if (C16) {
+              const uint32_t oc = rm_off32(c16m, row);
+              st32<half4>(C16, 2u * (oc + (uint32_t)rcolA), half4{cv[0], cv[1], cv[2], cv[3]});
+              if (rokB) st32<half4>(C16, 2u * (oc + (uint32_t)rcolB), half4{cv[4], cv[5], cv[6], cv[7]});
+            }
+            if (G16) {
+              const uint32_t og = rm_off32(g16m, row);
+              st32<half4>(G16, 2u * (og + (uint32_t)rcolA), half4{gv[0], gv[1], gv[2], gv[3]});
+              if (rokB) st32<half4>(G16, 2u * (og + (uint32_t)rcolB), half4{gv[4], gv[5], gv[6], gv[7]});
+            }
+          } else {
+            if (C16) st32<half8>(C16, 2u * (rm_off32(c16m, row) + (uint32_t)ecol), cv);
+            if (G16) st32<half8>(G16, 2u * (rm_off32(g16m, row) + (uint32_t)ecol), gv);
+          }
           if (side) {
             // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged half, LoRA-dropout
             // mask applied, for the MFMA pass below
@@ -504,9 +529,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
             f32x4 h0 = res[i][0], h1 = res[i][1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { h0[e] += (float)gv[e]; h1[e] += (float)gv[4 + e]; }
-            const uint32_t oh = 4u * (rm_off32(h32m, row) + (uint32_t)ecol);
-            st32<f32x4>(p.H32, oh, h0);
-            st32<f32x4>(p.H32, oh + 16u, h1);
+            const uint32_t oh = rm_off32(h32m, row);
+            st32<f32x4>(p.H32, 4u * (oh + (uint32_t)rcolA), h0);
+            if (rokB) st32<f32x4>(p.H32, 4u * (oh + (uint32_t)rcolB), h1);
           }
         }
       }

@@ -135,6 +135,6 @@ def test_persistent_gemm_k_loop_has_no_scratch(tmp_path):
         # around the second product's address set-up once cost these variants 25-45 registers and 7-12 % of their launches)
         n_scr = len(re.findall(r"scratch_(load|store)", text))
         if "ELi1E" in name:
-            assert n_scr <= 48, (name, n_scr)          # residual epilogue: the next tile's addresses are parked across the epilogue
+            assert n_scr <= 64, (name, n_scr)          # residual epilogue: the next tile's addresses are parked across the epilogue (26-36 dwords)
         else:
             assert n_scr == 0, (name, n_scr)
