@@ -13,9 +13,8 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKS = 32, NST = 4, NTH = 256;
-constexpr int HALF_BYTES = BM * BKS * 2;       // 8 KiB: one operand slice
-constexpr int STAGE_BYTES = 2 * HALF_BYTES;    // 16 KiB
+constexpr int BN = 128, BKS = 32, NST = 4, NTH = 256;     // BM = 128 or 64 (template): 64-row tiles when 128-row tiles leave most CUs idle
+constexpr int B_BYTES = BN * BKS * 2;          // 8 KiB: one B slice
 
 __device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -34,8 +33,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // K tails: chunks beyond the valid K range are fetched from a block of zeros, so the MFMA loop is branch-free
 __device__ __attribute__((aligned(16))) const uint32_t ns_zero_chunk128[4] = {0, 0, 0, 0};
 
-template <bool DROP>
+template <bool DROP, int BM>
 __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc p) {
+  constexpr int MI = BM / 64;                  // 32-row MFMA tiles per wave along M (wave grid 2 x 2: wave tile BM/2 x 64)
+  constexpr int A_BYTES = BM * BKS * 2;        // one A slice: 8 or 4 KiB
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int AP = BM / 64;                  // 1-KiB A pieces per wave and slice (B: always 2)
   const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,36 +68,38 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     Kloc = max(0, min(p.K, kbeg + per) - kbeg);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- DMA source pointers: this wave fills rows [32*wave, 32*wave+32) of both operand slices with
-  // two 1-KiB instructions each; lane -> (row = 16*j + lane/4, LDS chunk' = lane%4) <- global chunk' ^ swz(row)
+  // ---- DMA source pointers: this wave fills rows [32*wave, 32*wave+32) of the B slice with two 1-KiB instructions and rows
+  // [16*AP*wave, +16*AP) of the A slice with AP; lane -> (row = 16*piece + lane/4, LDS chunk' = lane%4) <- global chunk' ^ swz(row)
   const half_t* a_src[2];
   const half_t* b_src[2];
   const half_t* a2_src[2] = {nullptr, nullptr};
   const half_t* b2_src[2] = {nullptr, nullptr};
-  int my_chunk[2];
+  int a_chunk[2], b_chunk[2];
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) {
-    const int row = 16 * (wave * 2 + jj) + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    my_chunk[jj] = chunk;
-    a_src[jj] = (const half_t*)p.A + ns_rm_off64(p.am, min(m0 + row, p.M - 1)) + chunk * 8 + kbeg;
-    b_src[jj] = (const half_t*)p.B + (long long)min(n0 + row, p.N - 1) * p.bm.ld + chunk * 8 + kbeg;
+    const int brow = 16 * (wave * 2 + jj) + (lane >> 2);
+    b_chunk[jj] = (lane & 3) ^ ((brow >> 2) & 3);
+    b_src[jj] = (const half_t*)p.B + (long long)min(n0 + brow, p.N - 1) * p.bm.ld + b_chunk[jj] * 8 + kbeg;
+    const int arow = 16 * (wave * AP + (jj < AP ? jj : 0)) + (lane >> 2);
+    a_chunk[jj] = (lane & 3) ^ ((arow >> 2) & 3);
+    a_src[jj] = (const half_t*)p.A + ns_rm_off64(p.am, min(m0 + arow, p.M - 1)) + a_chunk[jj] * 8 + kbeg;
   }
   if (p.K2 > 0) {
     const int goff = p.a2_ngroup > 0 ? (n0 / p.a2_ngroup) * p.K2 : 0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      const int row = 16 * (wave * 2 + jj) + (lane >> 2);
-      a2_src[jj] = (const half_t*)p.A2 + ns_rm_off64(p.am2, min(m0 + row, p.M - 1)) + goff + my_chunk[jj] * 8;
-      b2_src[jj] = (const half_t*)p.B2 + (long long)min(n0 + row, p.N - 1) * p.ldb2 + my_chunk[jj] * 8;
+      const int brow = 16 * (wave * 2 + jj) + (lane >> 2);
+      const int arow = 16 * (wave * AP + (jj < AP ? jj : 0)) + (lane >> 2);
+      a2_src[jj] = (const half_t*)p.A2 + ns_rm_off64(p.am2, min(m0 + arow, p.M - 1)) + goff + a_chunk[jj] * 8;
+      b2_src[jj] = (const half_t*)p.B2 + (long long)min(n0 + brow, p.N - 1) * p.ldb2 + b_chunk[jj] * 8;
     }
   }
 
@@ -111,29 +116,33 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   };
   auto issue = [&](int s) __attribute__((always_inline)) {
     bool is2; int k0, klen; step_info(s, is2, k0, klen);
-    char* const dst = smem + (s % NST) * STAGE_BYTES + (wave * 2) * 1024;
+    char* const dst = smem + (s % NST) * STAGE_BYTES;
+#pragma unroll
+    for (int jj = 0; jj < AP; ++jj) {
+      const bool ok = a_chunk[jj] * 8 < klen;
+      glds16(ok ? (is2 ? a2_src[jj] : a_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + (wave * AP + jj) * 1024);
+    }
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      const bool ok = my_chunk[jj] * 8 < klen;
-      glds16(ok ? (is2 ? a2_src[jj] : a_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + jj * 1024);
-      glds16(ok ? (is2 ? b2_src[jj] : b_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + HALF_BYTES + jj * 1024);
+      const bool ok = b_chunk[jj] * 8 < klen;
+      glds16(ok ? (is2 ? b2_src[jj] : b_src[jj]) + k0 : (const half_t*)ns_zero_chunk128, dst + A_BYTES + (wave * 2 + jj) * 1024);
     }
   };
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* as = smem + buf * STAGE_BYTES;
-    const char* bs = as + HALF_BYTES;
-    half8 af[2][2], bf[2][2];
+    const char* bs = as + A_BYTES;
+    half8 af[2][MI], bf[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[s][i] = *(const half8*)(as + lds_off32(wm * 64 + i * 32 + lr, 2 * s + lh));
+      for (int i = 0; i < MI; ++i) af[s][i] = *(const half8*)(as + lds_off32(wm * (BM / 2) + i * 32 + lr, 2 * s + lh));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf[s][j] = *(const half8*)(bs + lds_off32(wn * 64 + j * 32 + lr, 2 * s + lh));
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
@@ -145,10 +154,10 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     if (s < nsteps) issue(s);
 
   for (int s = 0; s < nsteps; ++s) {
-    // slices s+1 .. min(s+NST-2, nsteps-1) may stay in flight (4 DMA instructions per slice per wave)
+    // slices s+1 .. min(s+NST-2, nsteps-1) may stay in flight
     const int ahead = min(NST - 2, nsteps - 1 - s);
-    if (ahead >= 2) wait_vmcnt<8>();
-    else if (ahead == 1) wait_vmcnt<4>();
+    if (ahead >= 2) wait_vmcnt<2 * (AP + 2)>();      // AP + 2 DMA instructions per slice and wave
+    else if (ahead == 1) wait_vmcnt<AP + 2>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // every wave's slice-s DMA has landed; every wave finished slice s-1
     asm volatile("" ::: "memory");
@@ -157,12 +166,12 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
     if (DROP && seg2_first && s == steps2 - 1) {
       const uint32_t drop_thr = ns_drop_thr8(p.drop_p);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const uint32_t row = (uint32_t)(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            const uint32_t row = (uint32_t)(m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
             const uint32_t col = (uint32_t)(n0 + wn * 64 + j * 32 + lr);
             acc[i][j][r] = ns_keep_el(dseed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
           }
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   if (gridDim.y > 1) {
     const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + lr;
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
         const float bz = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (row < p.M) atomicAdd(p.C32 + (long long)row * p.ldc32 + col, acc[i][j][r] * alpha + bz);
         }
       }
@@ -190,12 +199,12 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   __syncthreads();
   float* const ct = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         ct[row * BN + wn * 64 + j * 32 + lr] = acc[i][j][r];
       }
   __syncthreads();
@@ -206,15 +215,27 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
 
 // called by ns_gemm() for NT descriptors with N > 96 and no A-operand dropout (arguments already validated)
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
-  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  const size_t lds = NST * STAGE_BYTES;
+  const int tn = (d->N + BN - 1) / BN;
+  const int tiles128 = ((d->M + 127) / 128) * tn;
+  const int splits = ((d->flags & NS_GEMM_TN) || d->splits < 1) ? 1 : d->splits;   // > 1 only for the plain-C32 form (ns_gemm checks)
+  // 64-row tiles when 128-row tiles cover less than ~half of the CUs (the decoder-side GEMMs of a training step: 2816 rows x 512
+  // columns = 88 tiles): such launches are bound by what ONE CU can fetch, and 176 workgroups move 3/4 of the bytes per CU
+  const bool small = splits == 1 && tiles128 <= 128 && d->M > 64;
+  const size_t lds = NST * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
   static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   });
-  const int splits = ((d->flags & NS_GEMM_TN) || d->splits < 1) ? 1 : d->splits;   // > 1 only for the plain-C32 form (ns_gemm checks)
-  if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring_kernel<true>, dim3(tiles, splits), dim3(NTH), lds, st, *d);
-  else hipLaunchKernelGGL(ns_gemm_ring_kernel<false>, dim3(tiles, splits), dim3(NTH), lds, st, *d);
+  if (small) {
+    const int tiles = ((d->M + 63) / 64) * tn;
+    if (d->drop_p > 0.f) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 64>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
+    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 64>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
+  } else {
+    if (d->drop_p > 0.f) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 128>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
+    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 128>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
+  }
   return 0;
 }
