@@ -220,7 +220,7 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int splits = ((d->flags & NS_GEMM_TN) || d->splits < 1) ? 1 : d->splits;   // > 1 only for the plain-C32 form (ns_gemm checks)
   // 64-row tiles when 128-row tiles cover less than ~half of the CUs (the decoder-side GEMMs of a training step: 2816 rows x 512
   // columns = 88 tiles): such launches are bound by what ONE CU can fetch, and 176 workgroups move 3/4 of the bytes per CU
-  const bool small = splits == 1 && tiles128 <= 128 && d->M > 64;
+  const bool small = splits == 1 && tiles128 <= 384 && d->M > 64;
   const size_t lds = NST * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
   static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
   std::call_once(attr_once, [&] {
