@@ -6,7 +6,7 @@
 //   * the tile is 256 x 256 (128 flop per byte), 8 waves as 2 x 4 of 128 x 64, one workgroup per CU;
 //   * both operands travel by LDS-DMA (global_load_lds_dwordx4, inline asm: see ns_lora_bwd.hip for why) into a ring of
 //     four 32-row stages, issued THREE stages ahead; a stage is 32 reduction rows x 256 columns of each operand,
-//     row-major, with the 16-B chunks of a row XOR-swizzled by the row index on the SOURCE side, which makes the
+//     row-major, with the 16-B chunks of a row XOR-swizzled (t_swz of the row index) on the SOURCE side, which makes the
 //     transposed fragment reads (ds_read_b64_tr_b16) conflict-free without padding;
 //   * one counted s_waitcnt vmcnt + one raw s_barrier per stage; no staging registers;
 //   * the (tile, split) pairs are laid out split-major and dealt to the XCDs in contiguous runs, so the workgroups that
@@ -29,7 +29,12 @@ typedef __attribute__((address_space(3))) short4v lds_s4;
 
 __device__ __attribute__((aligned(16))) const uint32_t ns_t256_zero_chunk[4] = {0, 0, 0, 0};
 
-__device__ __forceinline__ int t_off(int row, int col) { return row * 512 + ((((col >> 3) ^ row) & 31) << 4) + ((col & 7) << 1); }
+// 16-B chunk c of image row r sits at chunk c ^ t_swz(r).  t_swz puts the row's low two bits into chunk bits 2-3: the four rows of one transposed
+// read (ds_read_b64_tr_b16: rows m .. m + 3, four neighbouring chunks each) land in four different 64-B windows of the 256-B bank span.  With the
+// plain c ^ r of before they permuted INSIDE one window: a 4-way conflict on every fragment read (SQ_LDS_BANK_CONFLICT 6.9e7 cycles per launch,
+// a third of the kernel's time).
+__device__ __forceinline__ int t_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int t_off(int row, int col) { return row * 512 + ((((col >> 3) ^ t_swz(row)) & 31) << 4) + ((col & 7) << 1); }
 
 // the 8 reduction rows m0 + 8 (lane >> 5) .. of column c0 + (lane & 31): two 4-row transposed reads
 __device__ __forceinline__ half8 t_frag(const char* img, int m0, int c0, int lane) {
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
   const int k_end = min(p.K, k_begin + chunk);
   const int nsteps = (max(k_end - k_begin, 0) + T_BK - 1) / T_BK;
 
-  // DMA pieces of this lane: stage rows 4 wave + 2 i + lh (i = 0, 1), LDS chunk lr <- global chunk lr ^ row
+  // DMA pieces of this lane: stage rows 4 wave + 2 i + lh (i = 0, 1), LDS chunk lr <- global chunk lr ^ t_swz(row)
   int seg[2], within[2];
   const half_t* srcA[2];
   const half_t* srcB[2];
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(T_NTH) void ns_gemm_tn256_kernel(const ns_gemm_desc
     const int rl = 4 * wave + 2 * i + lh, k = k_begin + rl;
     seg[i] = 0; within[i] = k;
     if (p.am.seg_rows > 0) { seg[i] = k / p.am.seg_rows; within[i] = k - seg[i] * p.am.seg_rows; }
-    const int cl = (lr ^ rl) & 31;
+    const int cl = (lr ^ t_swz(rl)) & 31;
     srcA[i] = (const half_t*)p.A + i0 + cl * 8;
     srcB[i] = (const half_t*)p.B + j0 + cl * 8;
     colB[i] = j0 + cl * 8 < p.N;

@@ -32,7 +32,11 @@ typedef __attribute__((address_space(3))) short4v lds_s4;
 
 __device__ __attribute__((aligned(16))) const uint32_t ns_lb_zero_chunk[4] = {0, 0, 0, 0};
 
-__device__ __forceinline__ int dy_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 31)) << 4); }
+// 16-B chunk c of image row r sits at chunk c ^ lb_swz(r): the row's low two bits go to chunk bits 2-3, so the four rows of a transposed read fall into
+// four different 64-B windows of the 256-B bank span (c ^ r permuted them inside ONE window: 4-way conflicts on every dy^T fragment), and the sixteen
+// rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27} ...) still get sixteen different chunk positions.
+__device__ __forceinline__ int lb_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int dy_off(int row, int chunk) { return row * 512 + ((chunk ^ lb_swz(row)) << 4); }
 
 // A[row = c0 + (lane & 31)][k = m0 + 8*(lane>>5) + i] of a 32x32x16 MFMA from a row-major [m][c] image: two 4-row
 // transposed reads (see ns_gemm_tn.hip tr_frag); `off(row, col)` is the byte offset of element (row, col)
@@ -71,7 +75,7 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_dst) {
 // Every operand of an item -- the dy slice (64 x 256), the sB^T slice (32 x 256) and, at a group's first slice, the chunk's
 // u rows -- travels by LDS-DMA into a ring of three slots, issued TWO items ahead of the one being multiplied: no staging
 // registers, ~100 KiB in flight per CU, and no register load in the loop for hipcc to fence.  The swizzle sits on the
-// per-lane SOURCE address (LDS chunk c' of row r <- global chunk c' ^ (r & 31)).  A wave issues 6 pieces per item (+ 2
+// per-lane SOURCE address (LDS chunk c' of row r <- global chunk c' ^ lb_swz(r)).  A wave issues 6 pieces per item (+ 2
 // four-byte pieces of u at a group's first slice); the counted wait at the top of an iteration leaves exactly the pieces of
 // the NEXT-BUT-ONE item in flight.
 template <int G, int NSUB>
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_de
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT_BYTES + wave * 4096);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = 8 * wave + 2 * i + lh, cl = lr ^ (row & 31);
+      const int row = 8 * wave + 2 * i + lh, cl = lr ^ lb_swz(row);
       const void* src = row0 + row < p.M ? (const void*)(dy + (long long)(row0 + row) * p.ldy + cl * 8) : (const void*)ns_lb_zero_chunk;
       glds16_asm(src, dst + i * 1024);
     }
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(NTH) void lora_bwd_dudb_kernel(const ns_lora_bwd_de
     const unsigned sdst = __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT_BYTES + DY_BYTES + wave * 2048);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = 4 * wave + 2 * i + lh, cl = lr ^ (row & 31);       // bottleneck row j
+      const int row = 4 * wave + 2 * i + lh, cl = lr ^ lb_swz(row);       // bottleneck row j
       const void* src = row < p.r ? (const void*)(sbt + (long long)row * p.N + cl * 8) : (const void*)ns_lb_zero_chunk;
       glds16_asm(src, sdst + i * 1024);
     }
