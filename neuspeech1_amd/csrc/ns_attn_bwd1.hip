@@ -316,7 +316,9 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
           const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(DSr + ds_off(k0, qg)));
           const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(DSr + ds_off(k0 + 4, qg)));
           const short8v a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), ktf[ks], acc, 0, 0, 0);
+          // K^T on the A port, dS on the B port: the lane then holds 4 consecutive d of ONE query row (dQ^T[d = 4 lg + e][q = l15]) -- one 8-byte
+          // store per lane in the last sweep, where the other orientation gave four 2-byte stores to four rows
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf[ks], __builtin_bit_cast(half8, a), acc, 0, 0, 0);
         }
       }
       if constexpr (HB) {
@@ -364,12 +366,9 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
 #endif
           ns_st<float4>(scr, scr_lane + (uint32_t)((t - 1) * 16 + qt) * 1024u, v);
         } else {
-          const int qb = q0 - QT + 32 * qh + 16 * qt + 4 * lg;
-          const uint32_t o = 2u * ((uint32_t)qb * p.lddq + 16 * dq + l15), ro = 2u * (uint32_t)p.lddq;
-          if (qb + 0 < p.Lq) ns_st<half_t>(dQ, o, (half_t)v.x);
-          if (qb + 1 < p.Lq) ns_st<half_t>(dQ, o + ro, (half_t)v.y);
-          if (qb + 2 < p.Lq) ns_st<half_t>(dQ, o + 2 * ro, (half_t)v.z);
-          if (qb + 3 < p.Lq) ns_st<half_t>(dQ, o + 3 * ro, (half_t)v.w);
+          const int qr = q0 - QT + 32 * qh + 16 * qt + l15;
+          const half4 o = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+          if (qr < p.Lq) ns_st<half4>(dQ, 2u * ((uint32_t)qr * p.lddq + 16 * dq + 4 * lg), o);
         }
       }
       if constexpr (HB) {       // used by the next iteration's half qt (a register pair per half: no copy of a value in flight)
