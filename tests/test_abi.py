@@ -23,3 +23,16 @@ def test_bad_arguments_fail_loudly_without_gpu():
     d = lib.GemmDesc()
     assert so.ns_gemm(C.byref(d), None) == -1
     assert b"ns_gemm" in so.ns_last_error()
+
+
+def test_attention_backward_workspace_rule():
+    """ns_attn_bwd_workspace_bytes (host-only): > 0 exactly where a one-pass backward exists -- unmasked attention over >= 256 keys with
+    >= 256 queries (fp32 dQ scratch, one 64 x 64 tile per step) or <= 64 queries (fp32 dQ slabs, one per group of key blocks)."""
+    from neuspeech1_amd import lib
+    so = lib.load()
+    f = so.ns_attn_bwd_workspace_bytes
+    assert f(64, 8, 1500, 1500, 0) == 64 * 8 * 24 * 64 * 64 * 4
+    few = f(64, 8, 44, 1500, 0)
+    assert few > 0 and few % (64 * 8 * 44 * 64 * 4) == 0 and few // (64 * 8 * 44 * 64 * 4) <= 6
+    for args in ((64, 8, 1500, 1500, 1), (64, 8, 44, 44, 1), (64, 8, 44, 200, 0), (64, 8, 100, 1500, 0), (64, 8, 200, 1500, 0)):
+        assert f(*args) == 0, args
