@@ -493,7 +493,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     // 9 = force its persistent form where it applies
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     const bool big = g_use_ring == 3 || g_use_ring == 4 || g_use_ring == 9 ||
-                     ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && d->M >= 2048 && tiles256 >= 192);
+                     ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && tiles256 >= 192 &&
+                      (d->M >= 2048 || (d->M >= 512 && d->N >= 8192)));      // (M >= 512 with a very wide N: the LM head of a beam-search step, 640 x 51 968: 58 us against 67 on the 128^2 ring)
     const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
