@@ -31,7 +31,9 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 # tiles, the position-row epilogue) and persistent (ns_gemm_p8s_kernel: >= 1024 tiles) -- one tile arithmetic, one "nt256" class in the
 # event-timed leg; in the rocprof stats its average launch = all ns_gemm_p8*_kernel rows together
 DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
-PMC_FILE = "profiles/r3_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
+PMC_FILE = "profiles/r4_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
+DECODE_PMC_FILE = "profiles/r4_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
+LV2_GFLOP_PER_SAMPLE = 5630.0   # whisper-large-v2, 273-ch, fwd+bwd
 
 
 def cpu_baseline(dims, r, alpha):
@@ -58,26 +60,33 @@ def cpu_baseline(dims, r, alpha):
             "sample": f"oracle fp32 fwd+bwd, whisper-base {dims.ch}-ch, B={B}, {n} timed passes after 1 warm-up"}
 
 
-def _kernel_source_hash():
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h"):
-        h.update(open(os.path.join(ROOT, "neuspeech1_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
-
-
 def _pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    need separate profiler runs, so they cannot be collected inside this process): profiles/r2_pmc_traffic.json, written
-    by tools/profile.sh pmc + tools/pmc_summary.py.  The file records the sha256 of the kernel's source; a file measured
-    on a different kernel revision is refused (traffic: null) rather than reported."""
+    need separate profiler runs, so they cannot be collected inside this process): PMC_FILE, written by
+    tools/profile.sh pmc + tools/pmc_summary.py.  The file records the hash of the kernel's comment- and whitespace-stripped
+    source (tools/kernel_hash.py); a file measured on a different kernel revision is refused (traffic: null) rather than
+    reported, and tests/test_profiles_cpu.py fails on such a file before it can reach the driver."""
     try:
+        from tools.kernel_hash import DOMINANT_SOURCES, source_hash
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        if not kernel or d.get("kernel") != kernel or d.get("kernel_source_sha256_16") != _kernel_source_hash():
+        if not kernel or d.get("kernel") != kernel or d.get("kernel_source_sha256_16") != source_hash(DOMINANT_SOURCES):
             return None
         return round(d["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
+def _decode_pmc_traffic():
+    """HBM bytes per decode STEP (greedy / beam-5) from the committed FETCH_SIZE / WRITE_SIZE passes over
+    tools/bench_decode.py (tools/profile.sh decode_pmc + tools/pmc_decode_summary.py), hash-guarded like _pmc_traffic"""
+    try:
+        from tools.kernel_hash import DECODE_SOURCES, source_hash
+        d = json.load(open(os.path.join(ROOT, DECODE_PMC_FILE)))
+        if d.get("kernel_source_sha256_16") != source_hash(DECODE_SOURCES):
+            return {}
+        return d.get("hbm_bytes_per_step", {})
+    except Exception:
+        return {}
 
 
 def cpu_reference_object(dims, B=4):
@@ -227,9 +236,52 @@ def eval_tokens_per_s(dev):
         t_mid = 4 + (n32 + n64) // 2                       # mean cache length over the differenced steps
         by = decode_bytes_per_step(dims, B, nb, t_mid)
         ach = by / (ms_step * 1e-3) / 1e9
+        tr = _decode_pmc_traffic().get(name)
         out["roofline"][name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                                  "frac_of_achievable_6300": round(ach / 6300.0, 4), "ms_per_step": round(ms_step, 4),
-                                 "algorithmic_bytes_per_step": by}
+                                 "algorithmic_bytes_per_step": by, "traffic": round(tr) if tr else None,
+                                 "traffic_source": DECODE_PMC_FILE}
+    return out
+
+
+def large_v2_leg(dev, B=32, steps=3):
+    """BASELINE configs[4] on the one GPU of this run: whisper-large-v2 (32 + 32 layers, d 1280), 273-ch, fp16 LoRA r = 32
+    (dropout 0.05) + conv-stem training step, B = 32 (B = 64 fits too: 169 GB): 1 warm-up (eager) + 1 capture + `steps`
+    timed graph replays.  Reported beside the headline, never as `value`."""
+    import torch
+    from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
+    from neuspeech1_amd.weights import WHISPER_LARGE_V2, make_state_dict, synth_batch
+    dims = WHISPER_LARGE_V2
+    t0 = time.perf_counter()
+    rng = torch.Generator(device=dev)
+    rng.manual_seed(42)
+
+    def gen(name, shape, std, seed, mean=0.0):      # random init of the architecture, drawn on the device
+        return torch.randn(tuple(shape) if not isinstance(shape, int) else (shape,), device=dev, generator=rng) * std + mean
+    sd = make_state_dict(dims, 42, gen=gen)
+    torch.manual_seed(42)
+    eng = MegWhisperEngine(dims, sd, lora=LoraSpec(r=32, alpha=64.0, dropout=0.05),
+                           train_cfg=TrainCfg(lr=1e-4, warmup_steps=0, total_steps=0), device=dev)
+    del sd
+    x, labels = synth_batch(dims, B, 1234)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    for _ in range(2):
+        eng.train_step(xd, ld)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = eng.train_step(xd, ld)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": f"whisper-large-v2 273-ch MEG (B,273,6000), fp16 LoRA r=32 (dropout 0.05) + conv-stem training step, bs{B}, "
+                       f"label len {labels.shape[1]}", "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2),
+           "steps": steps, "warmup": 2, "algorithmic_gflop_per_sample": LV2_GFLOP_PER_SAMPLE,
+           "whole_step_mfma_frac": round(B / dt * LV2_GFLOP_PER_SAMPLE * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
+           "final_loss": round(float(loss.item()), 4), "graph": eng.graph_stats(), "setup_s": round(t_setup, 1),
+           "mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    del eng
+    torch.cuda.empty_cache()
     return out
 
 
@@ -244,6 +296,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the decode (eval tokens/s) leg")
+    ap.add_argument("--no-large-v2", action="store_true", help="skip the whisper-large-v2 leg (BASELINE configs[4] at N = 1)")
     args = ap.parse_args()
 
     from neuspeech1_amd import build as _b
@@ -290,8 +343,7 @@ def main():
     x, labels = synth_batch(dims, B, 1234 + rank)    # disjoint shard per rank
     xd = torch.from_numpy(x).to(dev)
     ld = torch.from_numpy(labels).to(dev)
-    red = GradReducer(eng.G) if world > 1 else None
-    eng_graph = eng.use_graph
+    red = GradReducer(eng.G, timing=True) if world > 1 else None
 
     def step():
         if red is None:
@@ -322,6 +374,15 @@ def main():
         dt = t.item()
     loss_v = float(loss.item())
     value = world * B * args.steps / dt
+    # what the timed loop actually ran on, read AFTER it: a capture that failed and fell back to eager steps shows here
+    gstat = eng.graph_stats()
+    gstat["timed_steps_replayed"] = gstat["replays"] >= args.steps and gstat["capture_failures"] == 0
+    if world > 1:
+        flags = torch.tensor([gstat["replays"], gstat["capture_failures"], gstat["captures"]], device=dev, dtype=torch.int64)
+        allf = [torch.zeros_like(flags) for _ in range(world)]
+        dist.all_gather(allf, flags)
+        gstat["per_rank"] = [{"replays": int(f[0]), "capture_failures": int(f[1]), "captures": int(f[2])} for f in allf]
+        gstat["timed_steps_replayed"] = all(int(f[0]) >= args.steps and int(f[1]) == 0 for f in allf)
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -384,11 +445,16 @@ def main():
         except Exception as e:      # a reported baseline, not the product: never fail the bench line over it
             cpu = dict(cpu_port, note="reference-object leg failed: " + repr(e)[:160])
 
-    ev = None
+    ev = lv2 = None
     if rank == 0 and world == 1 and not args.no_eval:
         del eng
         torch.cuda.empty_cache()
         ev = eval_tokens_per_s(dev)
+        if not args.no_large_v2:
+            try:
+                lv2 = large_v2_leg(dev)
+            except Exception as e:      # a side leg: never fail the bench line over it
+                lv2 = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_eval:
         try:
             gpu_ref = gpu_reference_object(dev)
@@ -412,9 +478,10 @@ def main():
                        "whole_step_mfma_frac": round(value / world * gf * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4),
                        "encoder_fwd_bwd_mfma_frac": enc["mfma_frac"] if enc else None,
                        "final_loss": round(loss_v, 4),
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "train_step_graph": bool(eng_graph)},
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+                       "train_step_graph": bool(gstat["timed_steps_replayed"]), "graph": gstat},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "torch_rocm_reference_object": gpu_ref,
-            "encoder_fwd_bwd": enc, "dp": dp, "eval": ev,
+            "encoder_fwd_bwd": enc, "dp": dp, "eval": ev, "large_v2": lv2,
         }
         print(json.dumps(out), flush=True)
 

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, grad_flat: torch.Tensor, group=None, force: bool = False):
+    def __init__(self, grad_flat: torch.Tensor, group=None, force: bool = False, timing: bool = False):
         self.G = grad_flat
         self.group = group
         self.force = force        # run the collective even at world size 1 (tests of the stream / event plumbing)
@@ -28,15 +28,18 @@ class GradReducer:
         self.chunks = []
         self.bytes_per_step = 0
         self._waits = []          # (event before, event after) the optimizer stream's wait for the side stream, per step
-        # events are allocated ONCE and reused round-robin (a step records at most 3 chunk-ready events and, while the
-        # diagnosis is on, 2 + 2 x 3 timing events): nothing is created on the step path
-        self._ready_ev = [torch.cuda.Event() for _ in range(8)] if self.cuda else []
+        # chunk-ready events are allocated ONCE and reused round-robin (more than any step's chunk count): nothing is created
+        # on the step path.  `timing` (bench.py, tests; off in production) adds side-stream events around every chunk's
+        # collective and around the optimizer stream's wait: total vs exposed all-reduce time.  Each history entry OWNS its
+        # events (taken from a free list that retired entries feed), so a step with any number of chunks cannot re-record an
+        # event that an entry still in the history holds.
+        self._ready_ev = [torch.cuda.Event() for _ in range(16)] if self.cuda else []
         self._ready_i = 0
-        self.timing = True        # side-stream events around every chunk's collective (total vs exposed time); bench / tests
-        self._tpool, self._ti = [], 0
+        self.timing = timing
+        self._free_ev = []
         self._chunk_t = []        # per step: [(event before, event after) on the side stream per chunk]
         self._cur_t = []
-        self.keep = 256           # steps of timing history kept (ring)
+        self.keep = 256           # steps of timing history kept
 
     def on_ready(self, lo: int, hi: int):
         """G[lo:hi] is final on the current stream: start its all-reduce on the side stream."""
@@ -63,14 +66,8 @@ class GradReducer:
             self._reduce(view)
 
     def _tev(self):
-        """timing events from a ring sized for `keep` steps of history"""
-        n = self.keep * 8
-        if len(self._tpool) < n:
-            self._tpool.append(torch.cuda.Event(enable_timing=True))
-            return self._tpool[-1]
-        e = self._tpool[self._ti % n]
-        self._ti += 1
-        return e
+        """a timing event no history entry holds"""
+        return self._free_ev.pop() if self._free_ev else torch.cuda.Event(enable_timing=True)
 
     def _reduce(self, view):
         if self.native_avg:
@@ -91,8 +88,9 @@ class GradReducer:
                 self._waits.append((e0, e1, self.bytes_per_step))
                 self._chunk_t.append(self._cur_t)
                 self._cur_t = []
-                if len(self._waits) > self.keep:
-                    del self._waits[0], self._chunk_t[0]
+                if len(self._waits) > self.keep:        # the oldest entry retires: its events go back to the free list
+                    w, c = self._waits.pop(0), self._chunk_t.pop(0)
+                    self._free_ev += [w[0], w[1]] + [e for pair in c for e in pair]
             else:
                 cur.wait_stream(self.side)
         self.chunks.clear()

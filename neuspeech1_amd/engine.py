@@ -111,6 +111,17 @@ class _Lin:
         self.bias = b
 
 
+class _ResidentSignal:
+    """a batch that already sits packed in an engine-owned `xin` buffer (train_step's graph path packs plain fp32 batches
+    eagerly in front of the replay); quacks like feed.PackedSignal for encode()"""
+
+    def __init__(self, xin, shape):
+        self.xin, self.shape = xin, shape
+
+    def acquire(self):
+        return self
+
+
 class MegWhisperEngine:
     def __init__(self, dims: WhisperDims, sd: dict, lora: LoraSpec | None = None, lora_sd: dict | None = None,
                  train_cfg: TrainCfg | None = None, device="cuda:0", train_convs: bool = True):
@@ -188,6 +199,7 @@ class MegWhisperEngine:
         # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
         self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 48, 0
+        self._graph_captures = self._graph_failed_total = self._graph_replays = self._graph_evictions = 0
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
@@ -650,7 +662,7 @@ class MegWhisperEngine:
         dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
         B, T, S, Cp = b["B"], dims.T, dims.src_pos, dims.ch_pad
         M = B * S
-        if isinstance(x32, PackedSignal):       # on-GPU feed: the batch arrives already packed (feed.py)
+        if isinstance(x32, (PackedSignal, _ResidentSignal)):       # on-GPU feed: the batch arrives already packed (feed.py)
             assert x32.shape == (B, dims.ch, T) and x32.xin.shape == (B, T + 2, Cp)
             xin = x32.acquire().xin
         else:
@@ -1092,15 +1104,18 @@ class MegWhisperEngine:
         # ignore index so that a recipe needs a handful of graphs, not one per length.  Exactly neutral: padded positions are
         # ignored by the loss, lie behind every real position under the causal mask, and the loss is a mean over valid tokens.
         L = labels.shape[1]
-        Lp = (L + self.label_pad - 1) // self.label_pad * self.label_pad
+        Lp = min((L + self.label_pad - 1) // self.label_pad * self.label_pad, max(L, self.dims.tgt_pos))   # never past the position table
         if Lp != L:
             labels = torch.nn.functional.pad(labels, (0, Lp - L), value=-100)
         packed = isinstance(x32, PackedSignal)
-        xkey = x32.xin.data_ptr() if packed else x32.data_ptr()
+        cut = on_ready is not None or reduce_fn is not None
         # everything a captured launch argument was computed from: shapes, the input buffer, the exchange cuts, and the
-        # host-side settings that ride in kernel arguments (optimizer hyper-parameters, dropout rate, the seed base)
+        # host-side settings that ride in kernel arguments (optimizer hyper-parameters, dropout rate, the seed base).  A plain
+        # fp32 batch is a fresh tensor every step (a new address each time), so it is packed EAGERLY into the static `xin` of
+        # its batch size and the capture starts behind the pack: its key holds no input address.  A PackedSignal is one of the
+        # feed's few staging slots and is captured by address.
         import dataclasses
-        key = (tuple(x32.shape), tuple(labels.shape), xkey, on_ready is not None, dataclasses.astuple(self.tc),
+        key = (tuple(x32.shape), tuple(labels.shape), x32.xin.data_ptr() if packed else 0, cut, dataclasses.astuple(self.tc),
                self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs)
         g = self._graphs.get(key)
         if g is None:
@@ -1108,27 +1123,41 @@ class MegWhisperEngine:
             if warm not in self._graph_warm:
                 self._graph_warm.add(warm)
                 return self._train_step_eager(x32, labels, on_ready, reduce_fn)
+            prev_stream = torch.cuda.current_stream()
             try:
-                g = self._capture_step(x32, labels, on_ready is not None)
+                g = self._capture_step(x32, labels, cut)
+                self._graph_captures += 1
+                self._graph_failures = max(0, self._graph_failures - 1)     # strikes decay: three failures IN A ROW disable graphs
             except RuntimeError as e:
                 # another host thread outside this package's capture lock (e.g. torch's pin-memory thread) can invalidate a
-                # capture on HIP: nothing has executed, so run this step eagerly and try again later, a bounded number of times
+                # capture on HIP: nothing has executed, so run this step eagerly and try again later, a bounded number of times.
+                # torch.cuda.graph.__exit__ ends the capture BEFORE it leaves its side stream: when capture_end raises, the
+                # capture stream would stay current (the eager step, the prefetcher's wait_stream / record_stream and the
+                # allocator's stream ownership would all move to it) -- put the caller's stream back
                 torch.cuda.synchronize()
-                self._graph_failures += 1
-                if self._graph_failures >= 3:
+                torch.cuda.set_stream(prev_stream)
+                self._graph_failures += 2
+                self._graph_failed_total += 1
+                if self._graph_failures >= 6:
                     self.use_graph = False
                 import warnings
                 warnings.warn(f"train_step: hipGraph capture failed ({str(e).splitlines()[0][:120]}); eager step "
                               f"({'graphs disabled' if not self.use_graph else 'will retry'})")
                 return self._train_step_eager(x32, labels, on_ready, reduce_fn)
-            if len(self._graphs) >= self.graph_cache:        # label lengths / staging slots seen long ago: drop the oldest
+            if len(self._graphs) >= self.graph_cache:        # least recently used first (hits move a key to the end)
                 self._graphs.pop(next(iter(self._graphs)))
+                self._graph_evictions += 1
             self._graphs[key] = g
+        else:
+            self._graphs[key] = self._graphs.pop(key)        # LRU order
         if packed:
             x32.acquire()            # the copy stream's event: waited for eagerly, never inside a capture
+        else:
+            ops.signal_pack(x32, g["b"]["xin"], x32.shape[0], self.dims.ch, self.dims.T, self.dims.ch_pad)
         g["labels"].copy_(labels, non_blocking=True)
         self.training_mode = True
         self._b = g["b"]
+        self._graph_replays += 1
         for seg, hook in zip(g["segs"], g["hooks"]):
             seg.replay()
             if hook is not None:
@@ -1138,6 +1167,12 @@ class MegWhisperEngine:
                 elif on_ready is not None:
                     on_ready(*hook)
         return self.loss_dev if not self.adalora else self.total_loss_dev
+
+    def graph_stats(self) -> dict:
+        """what bench.py / finetune.py report AFTER a run: a capture that failed and fell back to eager steps must be visible"""
+        return {"enabled": bool(self.use_graph), "graphs_cached": len(self._graphs), "captures": self._graph_captures,
+                "capture_failures": self._graph_failed_total, "replays": self._graph_replays, "evictions": self._graph_evictions,
+                "segments": sorted({len(g["segs"]) for g in self._graphs.values()})}
 
     def _graph_usable(self, x32):
         if not (self.use_graph and self.dev.type == "cuda"):
@@ -1151,6 +1186,10 @@ class MegWhisperEngine:
         gradient chunk that is final there, "reduce" = the exchange must have completed)."""
         if isinstance(x32, PackedSignal):
             x32.acquire()
+        else:
+            # a plain fp32 batch: the caller packs it eagerly into the static `xin` of this batch size before every replay
+            # (train_step), the captured step starts behind the pack
+            x32 = _ResidentSignal(self._alloc_enc(x32.shape[0], True)["xin"], tuple(x32.shape))
         lab = labels.clone()
         torch.cuda.synchronize()
         segs, hooks = [], []

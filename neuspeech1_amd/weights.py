@@ -63,11 +63,13 @@ def _gen(name: str, shape, std: float, seed: int, mean: float = 0.0) -> np.ndarr
     return (mean + std * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
 
 
-def make_state_dict(dims: WhisperDims, seed: int = 42, frontend: str = "base") -> dict[str, np.ndarray]:
+def make_state_dict(dims: WhisperDims, seed: int = 42, frontend: str = "base", gen=None) -> dict[str, np.ndarray]:
     """HF-named fp32 state dict of Whisper with the MEG front-end installed
     (reference: utils/model_utils.py:9-23 replaces encoder.conv1 by a Sequential whose
-    state-dict keys are 0.weight/0.bias/2.weight/2.bias)."""
+    state-dict keys are 0.weight/0.bias/2.weight/2.bias).  `gen(name, shape, std, seed, mean)` replaces the numpy
+    generator (bench.py's large-v2 leg draws its 1.5 G random-init parameters on the device: 67 s of host time otherwise)."""
     d, f = dims.d, dims.ffn
+    _gen = gen or globals()["_gen"]
     sd: dict[str, np.ndarray] = {}
 
     def lin(prefix, out_f, in_f, bias=True):

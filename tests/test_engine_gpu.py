@@ -680,6 +680,105 @@ def test_graph_capture_with_gradient_exchange_hooks(dev):
     assert len(eng._graphs) == 1 and len(next(iter(eng._graphs.values()))["segs"]) == len(eager_log) + 1
 
 
+def test_graph_replay_with_rccl_exchange_single_rank(dev):
+    """What runs on an 8-GPU node, minus the wire: an RCCL process group alive (its watchdog thread included), the step
+    replayed from hipGraphs CUT at the exchange points, dp.GradReducer launching the chunks' all-reduce (AVG) eagerly on its
+    side stream between the replays and the optimizer segment waiting for them.  World size 1 (the collective is the
+    identity), so the replayed steps must equal an eager engine's; the capture must succeed once and never fail
+    (finetune.py:115-122,248 -> DDP in the reference)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from neuspeech1_amd.dp import GradReducer
+    dims = TINY
+    x, labels = synth_batch(dims, 3, 77)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng_a, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    eng_b, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    eng_a.use_graph = False
+    assert eng_b.use_graph
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        red = GradReducer(eng_b.G, force=True, timing=True)
+        dist.all_reduce(torch.ones(4, device=dev))      # communicator (and its watchdog) up before the first capture
+        torch.cuda.synchronize()
+        for step in range(9):
+            la = eng_a.train_step(xd, ld).item()
+            lb = eng_b.train_step(xd, ld, on_ready=red.on_ready, reduce_fn=red.finish).item()
+            assert abs(la - lb) < 1e-3 * max(1.0, abs(la)), (step, la, lb)
+            assert rel(eng_b.G, eng_a.G) < 1e-3, (step, rel(eng_b.G, eng_a.G))
+            eng_b.P.copy_(eng_a.P); eng_b.M1.copy_(eng_a.M1); eng_b.M2.copy_(eng_a.M2)
+            eng_b.refresh_operands()
+        torch.cuda.synchronize()
+        st = eng_b.graph_stats()
+        assert st["enabled"] and st["graphs_cached"] == 1 and st["captures"] == 1 and st["capture_failures"] == 0, st
+        assert st["replays"] == 8, st                      # first step of a shape eager, then capture + replay
+        # 3 exchange cuts (two adapter chunks + the conv stem) + "reduce" + the optimizer = 5 segments
+        assert st["segments"] == [5], st
+        assert red.total_ms() > 0.0 and red.exposed_ms()[1] == 4 * eng_b.n_train
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_capture_falls_back_and_restores_the_stream(dev):
+    """A capture that is invalidated (here: a device synchronize inside it, what a foreign host thread does) must not leave
+    torch's capture side stream current: the step falls back to eager on the CALLER's stream, the failure is counted and
+    reported, and the next attempt captures."""
+    dims = TINY
+    eng, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    x, labels = synth_batch(dims, 3, 77)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    eng.train_step(xd, ld)                       # warm step (eager)
+    cur = torch.cuda.current_stream()
+    real = eng.optimizer_step
+    in_capture = []
+
+    def bad_optimizer_step():
+        if torch.cuda.is_current_stream_capturing():
+            in_capture.append(1)
+            torch.cuda.synchronize()             # illegal during capture: invalidates it
+        real()
+    eng.optimizer_step = bad_optimizer_step
+    with pytest.warns(UserWarning, match="capture failed"):
+        l1 = eng.train_step(xd, ld)
+    assert in_capture and torch.cuda.current_stream() == cur
+    assert torch.isfinite(l1).all()
+    st = eng.graph_stats()
+    assert st["capture_failures"] == 1 and st["captures"] == 0 and st["enabled"]
+    eng.optimizer_step = real
+    for _ in range(3):
+        l2 = eng.train_step(xd, ld)
+    assert torch.cuda.current_stream() == cur and torch.isfinite(l2).all()
+    st = eng.graph_stats()
+    assert st["captures"] == 1 and st["replays"] == 3 and st["capture_failures"] == 1, st
+
+
+def test_plain_tensor_batches_share_one_graph(dev):
+    """Plain fp32 batches arrive as a fresh tensor (a new address) every step: the graph path packs them eagerly into the
+    engine's static xin, so ONE capture serves them all, and reduce_fn alone (no on_ready) still gets its hook."""
+    dims = TINY
+    eng, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    ref, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    ref.use_graph = False
+    calls = []
+    for s in range(6):
+        x, labels = synth_batch(dims, 3, 100 + s)
+        xd, ld = torch.from_numpy(x).to(dev).clone(), torch.from_numpy(labels).to(dev)
+        lg = eng.train_step(xd, ld, reduce_fn=lambda: calls.append(s)).item()
+        le = ref.train_step(xd, ld).item()
+        assert abs(lg - le) < 1e-3 * max(1.0, abs(le)), (s, lg, le)
+        assert rel(eng.G, ref.G) < 1e-3
+        eng.P.copy_(ref.P); eng.M1.copy_(ref.M1); eng.M2.copy_(ref.M2)
+        eng.refresh_operands()
+    st = eng.graph_stats()
+    assert st["graphs_cached"] == 1 and st["captures"] == 1 and st["replays"] == 5, st
+    assert calls == list(range(6))               # eager warm step + every replay
+
+
 def test_adalora_graph_replays_back_to_back_report_a_finite_regulariser(dev):
     """The reference's default adapter under graph replay WITHOUT host synchronisation between steps (how finetune.py and
     bench.py run): every step's reported loss (cross-entropy + orthogonality regulariser) must stay finite and follow the

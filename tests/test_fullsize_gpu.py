@@ -106,4 +106,4 @@ def test_b128_273ch_decode_rows_equal_golden_and_small_batch_decodes(dev, name, 
     # 128 differ).  Beam-5 + penalties on a flat random-init model weighs 10 candidates per row and step and keeps
     # near-ties alive: measured 9 of 128 rows end on a different hypothesis whose length-normalised score equals the
     # B = 2 one within 0.024 (asserted above: < 0.05).  An index, grid-size or slab bug would break most rows and their scores.
-    assert len(diff) <= (2 if nb == 1 else 20), diff
+    assert len(diff) <= (0 if nb == 1 else 11), diff      # measured 0 / 9 (+ 2 for box-to-box noise in the near-ties)

@@ -169,4 +169,6 @@ def test_greedy_ids_vs_live_fp16(dev, tag, dims, B, name, kw):
         flips.append((b, p, round(m, 4)))
     print(f"\n[{tag}/{name}] rows {B}, rows leaving the live fp16 run at a sub-threshold margin: {flips}; "
           f"min live margin {float(margin.min()):.4f}")
-    assert len(flips) <= B // 2      # ties are the exception, not the rule
+    # north_star: greedy token ids bit-identical to the reference.  Against the reference's OWN numerics (this live fp16 run) no row
+    # has ever left it: pinned at zero.
+    assert len(flips) == 0, flips

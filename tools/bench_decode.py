@@ -29,6 +29,27 @@ ONLY = os.environ.get("BEAMS")     # "1" or "5": one mode only (clean rocprofv3 
 SB = {}
 if os.environ.get("SB"):           # evaluation.py --add_sequence_bias: a small table of single- and multi-token entries
     SB = dict(sequence_bias={(7,): 2.0, (11, 12): 1.5, (20, 21, 22): 3.0, (300,): -1.0, (41, 42): 0.5})
+MARK = os.environ.get("MARK") == "1"     # tools/profile.sh decode_pmc: one run per (mode, length), a marker launch between them
+
+
+def mark():
+    """a launch no decode step issues (torch's scan kernel): tools/pmc_decode_summary.py cuts the dispatch list at it"""
+    torch.cumsum(torch.ones(64, device=dev), 0)
+
+
+if MARK:
+    modes = ((1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2)))
+    for nb, kw in modes:         # warm-up: lazy allocations (and their fills) stay out of the counted runs
+        gen.generate(x, prompt, num_beams=nb, max_new_tokens=8, suppress_tokens=[dims.eos_id], check_every=8, **kw)
+    torch.cuda.synchronize()
+    mark()
+    for nb, kw in modes:
+        for new in (NEW, NEW // 2):
+            out = gen.generate(x, prompt, num_beams=nb, max_new_tokens=new, suppress_tokens=[dims.eos_id], check_every=8, **kw)
+            torch.cuda.synchronize()
+            mark()
+            print(f"segment beams={nb} new={out.shape[1] - 4}", flush=True)
+    sys.exit(0)
 for nb, kw in ((1, dict(SB)), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2, **SB))):
     if ONLY and int(ONLY) != nb:
         continue

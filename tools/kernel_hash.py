@@ -1,0 +1,34 @@
+"""Identity of a kernel's SOURCE for the PMC evidence files under profiles/: the sha256 of the named csrc files with
+comments and whitespace removed, so that a comment edit does not orphan a rocprofv3 pass (round 3: a two-line comment
+made bench.py refuse profiles/r3_pmc_traffic.json and the driver's line carried `traffic: null`).  bench.py reports a
+counter file only while this hash equals the one recorded in it; tests/test_profiles_cpu.py fails when they differ."""
+import hashlib
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neuspeech1_amd", "csrc")
+# the dominant training kernel (bench.py: DOMINANT) and what its tile arithmetic / epilogues are written in
+DOMINANT_SOURCES = ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h")
+# one decode step: attention over the caches, small-M projections, LayerNorm, selection
+DECODE_SOURCES = ("ns_decode.hip", "ns_gemm_smallm.hip", "ns_gemm.hip", "ns_norm.hip")
+
+_COMMENT = re.compile(r"//[^\n]*|/\*.*?\*/", re.S)
+
+
+def stripped(text: str) -> str:
+    """C / C++ comments and all whitespace removed (string literals in these files hold no comment markers)"""
+    return re.sub(r"\s+", "", _COMMENT.sub(" ", text))
+
+
+def source_hash(files=DOMINANT_SOURCES) -> str:
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(CSRC, f), encoding="utf-8") as fh:
+            h.update(stripped(fh.read()).encode())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print("dominant", source_hash(DOMINANT_SOURCES))
+    print("decode", source_hash(DECODE_SOURCES))

@@ -1,10 +1,10 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE rocprofv3 passes of tools/profile.sh pmc <tag> into
-gpurun_out/pmc_<tag>_traffic.json (copy it to profiles/r3_pmc_traffic.json): HBM bytes per launch of every kernel,
+gpurun_out/pmc_<tag>_traffic.json (copy it to profiles/r4_pmc_traffic.json): HBM bytes per launch of every kernel,
 FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md §HBM), WRITE_SIZE as is; both counters
-are in KB.  The record carries the sha256 of the dominant kernel's source so that bench.py can refuse a stale file."""
+are in KB.  The record carries the hash of the dominant kernel's comment-stripped source (tools/kernel_hash.py) so that bench.py can
+refuse a stale file."""
 import csv
 import glob
-import hashlib
 import json
 import os
 import sys
@@ -13,11 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
+sys.path.insert(0, ROOT)
+from tools.kernel_hash import DOMINANT_SOURCES, source_hash  # noqa: E402
+
+
 def kernel_source_hash():
-    h = hashlib.sha256()
-    for f in ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h"):
-        h.update(open(os.path.join(ROOT, "neuspeech1_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    return source_hash(DOMINANT_SOURCES)
 
 
 def per_kernel(tag, counter):
