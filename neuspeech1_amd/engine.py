@@ -200,6 +200,7 @@ class MegWhisperEngine:
         self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
         self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 48, 0
         self._graph_captures = self._graph_failed_total = self._graph_replays = self._graph_evictions = 0
+        self._graph_graveyard = []
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
@@ -1229,6 +1230,10 @@ class MegWhisperEngine:
                         state["ctx"].__exit__(None, None, None)
                     except Exception:
                         pass
+                # graph objects of a capture that did not end cleanly are never destroyed: torch's ~CUDAGraph of such an object
+                # aborted the process on the GPU box (a check that throws inside a destructor) when the frames of this call
+                # were released; a failed capture is rare and its objects are small
+                self._graph_graveyard.append((state["g"], segs, pool))
                 raise
         return {"segs": segs, "hooks": hooks, "labels": lab, "b": self._b}
 

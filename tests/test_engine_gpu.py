@@ -725,7 +725,7 @@ def test_graph_replay_with_rccl_exchange_single_rank(dev):
 
 
 def test_failed_capture_falls_back_and_restores_the_stream(dev):
-    """A capture that is invalidated (here: a device synchronize inside it, what a foreign host thread does) must not leave
+    """A capture that is invalidated (here: ANOTHER host thread synchronises the device while it is open) must not leave
     torch's capture side stream current: the step falls back to eager on the CALLER's stream, the failure is counted and
     reported, and the next attempt captures."""
     dims = TINY
@@ -740,7 +740,19 @@ def test_failed_capture_falls_back_and_restores_the_stream(dev):
     def bad_optimizer_step():
         if torch.cuda.is_current_stream_capturing():
             in_capture.append(1)
-            torch.cuda.synchronize()             # illegal during capture: invalidates it
+
+            def foreign():                       # what torch's pin-memory thread or a user thread may do at any time
+                torch.cuda.set_device(dev)
+                try:
+                    torch.cuda.synchronize(dev)
+                except RuntimeError:
+                    pass
+            import threading
+            real()                               # every launch of the step is captured; the capture is invalidated just before it ends
+            th = threading.Thread(target=foreign)
+            th.start()
+            th.join()
+            return
         real()
     eng.optimizer_step = bad_optimizer_step
     with pytest.warns(UserWarning, match="capture failed"):
