@@ -23,31 +23,40 @@ namespace {
 template <bool VEC4>
 __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restrict__ x, half_t* __restrict__ out, int ch,
                                                            int T, int Cp) {
-  constexpr int LDT = 72;                               // halfs per tile row: 144 B keeps 16-B alignment and spreads the banks
-  __shared__ __attribute__((aligned(16))) half_t tile[64 * LDT];     // [time][channel]
+  // tile [time 64][channel 64] fp16, 128-B rows; 16-B chunk c of time row t sits at chunk c ^ ((t >> 2) & 7).  Round 3 stored single
+  // halfs into 144-B rows: the 16 time groups of a wave instruction fell on two banks (SQ_LDS_BANK_CONFLICT 6x the LDS instruction
+  // cycles).  Now a thread owns channel PAIRS and writes dwords: 16 banks per 32 lanes (2-way, free for ds_write_b32), and the
+  // ds_read_b128 of the way out is conflict-free (the four rows of a lane group differ in bit 5 of the bank or in the chunk).
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 128];
   const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
   const float* xb = x + (size_t)b * ch * T;
   if (VEC4) {
-    const int cl = threadIdx.x >> 4, tl4 = (threadIdx.x & 15) * 4;
+    const int cl = threadIdx.x >> 4, k = threadIdx.x & 15, tl4 = 4 * k;
     float4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = c0 + cl + 16 * i, t = t0 + tl4;
+      const int c = c0 + 2 * cl + (i & 1) + 32 * (i >> 1), t = t0 + tl4;
       v[i] = (c < ch && t < T) ? *(const float4*)(xb + (size_t)c * T + t) : make_float4(0.f, 0.f, 0.f, 0.f);   // T % 4 == 0: t + 3 < T
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      half_t* col = tile + tl4 * LDT + cl + 16 * i;
-      col[0] = (half_t)v[i].x; col[LDT] = (half_t)v[i].y; col[2 * LDT] = (half_t)v[i].z; col[3 * LDT] = (half_t)v[i].w;
+    for (int pr = 0; pr < 2; ++pr) {
+      const float lo[4] = {v[2 * pr].x, v[2 * pr].y, v[2 * pr].z, v[2 * pr].w};
+      const float hi[4] = {v[2 * pr + 1].x, v[2 * pr + 1].y, v[2 * pr + 1].z, v[2 * pr + 1].w};
+      const int chunk = (cl >> 2) + 4 * pr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const half2v h = {(half_t)lo[e], (half_t)hi[e]};
+        *(half2v*)(tile + (tl4 + e) * 128 + ((chunk ^ (k & 7)) << 4) + (cl & 3) * 4) = h;
+      }
     }
   } else {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-      const int c = c0 + w * 16 + i, t = t0 + lane;
+      const int cc_ = w * 16 + i, c = c0 + cc_, t = t0 + lane;
       float v = 0.f;
       if (c < ch && t < T) v = xb[(size_t)c * T + t];
-      tile[lane * LDT + w * 16 + i] = (half_t)v;
+      *(half_t*)(tile + lane * 128 + (((cc_ >> 3) ^ ((lane >> 2) & 7)) << 4) + (cc_ & 7) * 2) = (half_t)v;
     }
   }
   __syncthreads();
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restric
   for (int it = 0; it < 2; ++it) {
     const int tl = (threadIdx.x >> 3) + 32 * it;
     const int t = t0 + tl;
-    if (t < T) *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = *(const half8*)(tile + tl * LDT + cc);
+    if (t < T) *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = *(const half8*)(tile + tl * 128 + (((cc >> 3) ^ ((tl >> 2) & 7)) << 4));
   }
   // halo rows
   if (blockIdx.x == 0 && threadIdx.x < 64) {

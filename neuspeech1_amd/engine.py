@@ -204,6 +204,7 @@ class MegWhisperEngine:
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
+        self.no_ln_lora = os.environ.get("NS_NO_LN_LORA") == "1"   # tests / A-B runs: LayerNorm and the adapter down-projection as two launches
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
@@ -707,10 +708,19 @@ class MegWhisperEngine:
                 hin, hmid, hout = h[0], h[1], h[0]
             lo = self.lora_ops[i] if r else None
             seed = self._layer_seed(i)
-            ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
+            # LayerNorm and the adapter bottleneck of the Linear it feeds in ONE pass over the residual stream where the fused
+            # kernel is built (ns_layernorm_fwd_lora: u bitwise equal to the separate down-projection launch)
+            fuse_ln = bool(r) and not self.no_ln_lora and ops.layernorm_fwd_lora_supported(M, d, 3 * r) and \
+                ops.layernorm_fwd_lora_supported(M, d, r)
+            if fuse_ln:
+                ops.layernorm_fwd_lora(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d, lo["Aqkv"], d, 3 * r, b["uqkv"][j], 3 * r,
+                                       alpha=self._drop_inv(), drop_p=dp, drop_seed=seed, seed_dev=self.seed_ctr if dp > 0 else None)
+            else:
+                ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
             if r:
-                self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
-                         c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
+                if not fuse_ln:
+                    self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
+                             c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
                 self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j], A2=b["uqkv"][j], lda2=3 * r, K2=r, B2=lo["sBqkv"],
                           ngroup=d)
             else:
@@ -724,10 +734,15 @@ class MegWhisperEngine:
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"])
             else:
                 self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid)
-            ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
+            if fuse_ln:
+                ops.layernorm_fwd_lora(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d, lo["fc1_A"], d, r, b["u1"][j], r,
+                                       alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2, seed_dev=self.seed_ctr if dp > 0 else None)
+            else:
+                ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
             if r:
-                self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
-                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
+                if not fuse_ln:
+                    self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
+                             flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
                 side = train and "u2_slabs" in b and not self.no_side_u2
                 sk = dict(side_B=lo["fc2_A"], side_ldb=f, side_n=r, side_out=b["u2_slabs"], side_drop_p=dp,
                           side_drop_seed=seed + 3) if side else {}
@@ -1117,7 +1132,7 @@ class MegWhisperEngine:
         # feed's few staging slots and is captured by address.
         import dataclasses
         key = (tuple(x32.shape), tuple(labels.shape), x32.xin.data_ptr() if packed else 0, cut, dataclasses.astuple(self.tc),
-               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs)
+               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs, self.no_ln_lora)
         g = self._graphs.get(key)
         if g is None:
             warm = (tuple(x32.shape), tuple(labels.shape))

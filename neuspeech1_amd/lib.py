@@ -179,6 +179,8 @@ SIGNATURES = {
     "ns_debug_set_ring": (None, [C.c_int]),
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ns_layernorm_fwd_lora_supported": (C.c_int, [_i, _i, _i]),
+    "ns_layernorm_fwd_lora": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _i, _f, _f, C.c_uint32, _vp, _vp]),
     "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ns_feed_pack": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ns_embed_pos": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

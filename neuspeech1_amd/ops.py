@@ -101,6 +101,18 @@ def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5
                                       rows, d, eps, _stream()), "ns_layernorm_fwd")
 
 
+def layernorm_fwd_lora_supported(rows, d, n_out):
+    return bool(L.load().ns_layernorm_fwd_lora_supported(rows, d, n_out))
+
+
+def layernorm_fwd_lora(x32, gamma, beta, y16, mean, rstd, rows, d, A16, lda, n_out, u16, ldu, alpha=1.0, drop_p=0.0, drop_seed=0,
+                       seed_dev=None, eps=1e-5):
+    """y16 = LN(x32) and u16 = round16(alpha * drop(y16) A16^T) in one pass (ns_layernorm_fwd_lora)"""
+    L.check(L.load().ns_layernorm_fwd_lora(ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(mean), ptr(rstd), rows, d, eps, ptr(A16), lda,
+                                           n_out, ptr(u16), ldu, alpha, drop_p, int(drop_seed) & 0xFFFFFFFF, ptr(seed_dev), _stream()),
+            "ns_layernorm_fwd_lora")
+
+
 def layernorm_bwd(dy, dy_is_f32, x32, mean, rstd, gamma, dres, dx32, dx16, rows, d):
     L.check(L.load().ns_layernorm_bwd(ptr(dy), int(dy_is_f32), ptr(x32), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
                                       ptr(dx32), ptr(dx16), rows, d, _stream()), "ns_layernorm_bwd")
