@@ -12,6 +12,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ns_u4v __attribute__((ext_vector_type(4)));   // a 128-bit inline-asm operand (HIP's uint4 is a struct)
 
 // few-query one-pass attention backward (ns_attn.hip attn_bwd_fewq_kernel): key blocks of 128 per workgroup = keys per fp32 dQ slab / 128
 #ifndef NS_FEWQ_KPW
@@ -42,9 +43,14 @@ void ns_set_error(const char* fmt, ...);
 // exact-erf GELU (torch.nn.functional.gelu default) evaluated with the Abramowitz-Stegun 7.1.26 rational form of
 // erf (|error| <= 1.5e-7, far below the fp16 rounding of every value these feed): ~12 VALU + one exp + one rcp
 // instead of libm's branchy erff.  The same exp(-x^2/2) serves the pdf term of the derivative.
+// 1 / x as ONE v_rcp_f32 (1 ulp).  __frcp_rn compiles to the correctly rounded division sequence (v_div_scale x 2, v_rcp, five fma,
+// v_div_fmas, v_div_fixup: 11 instructions per element -- a fifth of the GELU epilogue's VALU stream, found in the ISA of the fc1
+// launches in round 4); the argument here is 1 + 0.33 |x| / sqrt2 in [1, 16], and a 6e-8 relative error in t moves erf by less than the
+// 1.5e-7 of the rational form itself.
+__device__ __forceinline__ float ns_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ void ns_gelu_terms(float x, float& cdf, float& pdf) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = ns_rcp(1.0f + 0.3275911f * z);
   const float e = __expf(-z * z);                       // = exp(-x^2/2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * e;                // erf(|x|/sqrt2)
@@ -69,7 +75,7 @@ __device__ __forceinline__ void ns_gelu_both2(ns_f2 x, ns_f2& g, ns_f2& dg) {
   const ns_f2 ax = {fabsf(x.x), fabsf(x.y)};
   const ns_f2 z = ax * 0.70710678118654752440f;
   const ns_f2 den = z * 0.3275911f + 1.0f;
-  const ns_f2 t = {__frcp_rn(den.x), __frcp_rn(den.y)};
+  const ns_f2 t = {ns_rcp(den.x), ns_rcp(den.y)};
   const ns_f2 nz2 = -z * z;
   const ns_f2 e = {__expf(nz2.x), __expf(nz2.y)};
   ns_f2 poly = t * 1.061405429f + -1.453152027f;
@@ -114,8 +120,8 @@ __device__ __forceinline__ float ns_drop_inv(float p) { return 256.0f / (256.0f 
 // dwords of half2 AND-masks.
 __device__ __forceinline__ void ns_keep_masks(uint32_t w, uint32_t thr8, uint32_t& m01, uint32_t& m23) {
   const uint32_t ge = (((w & 0x7F7F7F7Fu) + (0x80u - thr8) * 0x01010101u) | w) & 0x80808080u;
-  const uint32_t f = ge >> 7;            // bytes 0 / 1
-  const uint32_t ff = (f << 8) - f;      // bytes 0x00 / 0xFF
+  const uint32_t ff = (ge - (ge >> 7)) | ge;   // bytes 0x00 / 0xFF: 0x80 - 0x01 = 0x7F per kept byte (no borrow across bytes), | 0x80
+                                                // ((f << 8) - f on the 0 / 1 bytes came out of hipcc as a quarter-rate v_mul_lo_u32 by 0xff)
   m01 = __builtin_amdgcn_perm(ff, ff, 0x01010000u);
   m23 = __builtin_amdgcn_perm(ff, ff, 0x03030202u);
 }

@@ -478,6 +478,12 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         {
+          // the two waves of a SIMD run the same VALU-bound row loop (GELU: ~37 instructions per element pair); at equal priority the
+          // older wave wins every issue arbitration, finishes its rows at 11.7 k cycles and leaves the younger one to issue alone at
+          // half rate until 17.5 k (in-kernel stamps, fc1 shape).  Alternating the priority row by row keeps both in the loop together.
+          if (KIND != NS_EPI_RES && do_gelu) {
+            if ((i & 1) == wm) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+          }
           const int rl = er0 + 16 * i, row = grow(hh, rl);
           if (!(KIND == NS_EPI_RES ? rokA : ecolok) || row >= p.M) continue;
           half8 v = vst[i];
@@ -500,6 +506,23 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
               if (save_grad) { cv[e] = (half_t)dg_.x; cv[e + 1] = (half_t)dg_.y; }
             }
           }
+          if (side) {
+            // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged half, LoRA-dropout
+            // mask applied, for the MFMA pass below.  BEFORE the row's global stores: placed behind them, the masks were ANDed in
+            // place onto the registers the stores had just been given, and hipcc protected that write-after-read with
+            // s_waitcnt vmcnt(0) -- a full store round trip per row, sixteen per tile of every fc1 launch.
+            uint4 w = __builtin_bit_cast(uint4, gv);
+            if (side_thr) {
+              uint32_t mk[4];
+              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
+              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
+              w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
+            }
+            // an asm store: behind a C++ store to LDS hipcc waits vmcnt(0) for the next tile's LDS-DMA pieces in flight (it models them as LDS
+            // stores that might alias) AND for this row's global stores -- a full round trip per row, sixteen per tile of every fc1 launch.
+            // The pieces land in ring buffer 0 / the bias slot, never in the staged tile; the MFMA pass below reads it behind lgkmcnt(0) + barrier.
+            asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(hs + rl * LDH + ecg * 16)), "v"(ns_u4v{w.x, w.y, w.z, w.w}) : "memory");
+          }
           if (KIND == NS_EPI_RES) {
             if (C16) {
               const uint32_t oc = rm_off32(c16m, row);
@@ -515,18 +538,6 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
             if (C16) st32<half8>(C16, 2u * (rm_off32(c16m, row) + (uint32_t)ecol), cv);
             if (G16) st32<half8>(G16, 2u * (rm_off32(g16m, row) + (uint32_t)ecol), gv);
           }
-          if (side) {
-            // side product (see ns_gemm_desc): the GELU values go back to this thread's own place in the staged half, LoRA-dropout
-            // mask applied, for the MFMA pass below
-            uint4 w = __builtin_bit_cast(uint4, gv);
-            if (side_thr) {
-              uint32_t mk[4];
-              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
-              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
-              w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
-            }
-            *(uint4*)(hs + rl * LDH + ecg * 16) = w;
-          }
           if (KIND == NS_EPI_RES) {
             f32x4 h0 = res[i][0], h1 = res[i][1];
 #pragma unroll
@@ -537,6 +548,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           }
         }
       }
+      if (KIND != NS_EPI_RES && do_gelu) __builtin_amdgcn_s_setprio(0);
       if (side) {
         // side_out[tn][m][j] = sum_n gm[m][n] side_B[j][n0 + n] over this tile's 256 columns: wave w takes staged rows 16 w .. 16 w + 15
         // x 32 adapter rows (two 16-row tiles) x 8 steps of 32 columns; side_B on the MFMA A port (a lane owns 4 consecutive j of a row)

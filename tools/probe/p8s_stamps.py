@@ -4,8 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from neuspeech1_amd import ops, lib
 from neuspeech1_amd.ops import rowmap
 dev = torch.device("cuda:0")
-CASES = [(96000, 1536, 512, "c16"), (96000, 512, 512, "res")]
-for mode in (4, 9):
+CASES = [(96000, 2048, 512, "gelu"), (96000, 2048, 512, "gelu_side")]
+MODES = (9,)
+for mode in MODES:
   lib.load().ns_debug_set_ring(mode)
   for M, N, K, epi in CASES:
     A = torch.randn(M, K, device=dev).half(); B = (torch.randn(N, K, device=dev) * 0.02).half()
@@ -20,7 +21,13 @@ for mode in (4, 9):
         kw.update(bias=torch.randn(N, device=dev), R32=R, H32=H, h32m=rowmap(N), flags=1 << 27)
     else:
         G = torch.empty_like(C)
-        kw.update(bias=torch.randn(N, device=dev), C16=C, c16m=rowmap(N), G16=G, g16m=rowmap(N), flags=1 | (1 << 27))
+        kw.update(bias=torch.randn(N, device=dev), C16=C, c16m=rowmap(N), G16=G, g16m=rowmap(N), flags=1 | 32 | (1 << 27))
+        if epi == "gelu_nograd":
+            kw.update(flags=1 | (1 << 27), C16=None, c16m=None)
+        if epi == "gelu_side":
+            SB = (torch.randn(32, N, device=dev) * 0.05).half()
+            slabs = torch.empty((N // 256) * M * 32, device=dev)
+            kw.update(side_B=SB, side_ldb=N, side_n=32, side_out=slabs, side_drop_p=0.05, side_drop_seed=7)
     for _ in range(3):
         ops.gemm(**kw)
     torch.cuda.synchronize()
