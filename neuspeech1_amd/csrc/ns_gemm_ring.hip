@@ -180,17 +180,27 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
 
   if (gridDim.y > 1) {
     const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
+    // the bias values FIRST, settled once: with the load next to its use, every atomic sat behind its own s_waitcnt vmcnt(0) (the
+    // use is inside a row-predicated block, where hipcc re-waits), i.e. behind the completion of every atomic before it -- a chain of
+    // 16 x MI x 2 memory round trips per lane (found in the ISA in round 4: the LM-head dgrad ran at 0.2 of the MFMA peak)
+    float bz[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = min(n0 + wn * 64 + j * 32 + lr, p.N - 1);
+      bz[j] = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bz[j]));
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + lr;
         if (col >= p.N) continue;
-        const float bz = (p.bias && blockIdx.y == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < p.M) atomicAdd(p.C32 + (long long)row * p.ldc32 + col, acc[i][j][r] * alpha + bz);
+          if (row < p.M) atomicAdd(p.C32 + (long long)row * p.ldc32 + col, acc[i][j][r] * alpha + bz[j]);
         }
       }
     return;
