@@ -204,7 +204,11 @@ class MegWhisperEngine:
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
-        self.no_ln_lora = os.environ.get("NS_NO_LN_LORA") == "1"   # tests / A-B runs: LayerNorm and the adapter down-projection as two launches
+        # LayerNorm fused with the adapter down-projection it feeds (ns_layernorm_fwd_lora, bitwise the two launches' results): OFF by
+        # default.  Measured in round 4: 25 % faster than the pair on cold operands, but inside the step both launches are served by the
+        # Infinity Cache (the LayerNorm input was just written) and the one-workgroup-per-CU fused kernel takes 68 / 77 us against
+        # 24 + 25 / 24 + 33 us (profiles/r4_a_bench_kernel_stats.csv).  NS_LN_LORA=1 turns it on.
+        self.no_ln_lora = os.environ.get("NS_LN_LORA") != "1"
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables

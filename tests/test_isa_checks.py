@@ -138,3 +138,46 @@ def test_persistent_gemm_k_loop_has_no_scratch(tmp_path):
             assert n_scr <= 64, (name, n_scr)          # residual epilogue: the next tile's addresses are parked across the epilogue (26-36 dwords)
         else:
             assert n_scr == 0, (name, n_scr)
+
+
+def test_gelu_epilogues_hold_no_division_sequence(tmp_path):
+    """Round 4, found in the ISA of the fc1 launches: `__frcp_rn` compiles to the correctly rounded division (v_div_scale x 2, v_rcp,
+    five fma, v_div_fmas, v_div_fixup: 11 instructions per element, a fifth of the GELU epilogue's VALU stream, 0.4 ms per step).
+    ns_gelu_* take ONE v_rcp_f32 (ns_rcp): no GEMM kernel may contain a v_div_scale / v_div_fixup again."""
+    for src in ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm.hip", "ns_gemm_ring.hip", "ns_gemm_ring256.hip"):
+        asm = _asm(src, tmp_path)
+        assert "v_div_scale_f32" not in asm and "v_div_fixup_f32" not in asm, src
+        assert "v_rcp_f32" in asm, src           # the GELU epilogue is still there
+
+
+def test_side_product_write_back_does_not_wait_for_vector_memory(tmp_path):
+    """ns_gemm_p8s_kernel, plain epilogue with the GELU side product: the masked GELU values go back into the staged tile with an
+    inline-asm ds_write_b128.  As a C++ store hipcc put `s_waitcnt vmcnt(0)` in front of it (it models the next tile's LDS-DMA
+    pieces in flight as LDS stores that might alias): one full vector-memory drain per row, sixteen per tile."""
+    ks = {k: v for k, v in _kernels(_asm("ns_gemm_p8s.hip", tmp_path)).items() if "ns_gemm_p8s_kernel" in k and "ELi0E" in k}
+    assert len(ks) == 4
+    for name, body in ks.items():
+        lines = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
+        n = 0
+        for i, l in enumerate(lines):
+            if l.startswith("s_waitcnt vmcnt(0)") and any(x.startswith("ds_write") for x in lines[i + 1:i + 4]):
+                n += 1
+        assert n <= 1, (name, n)
+        assert sum(1 for l in lines if l.startswith("s_waitcnt vmcnt(0)")) <= 8, name
+
+
+def test_split_k_atomics_are_not_serialised(tmp_path):
+    """ns_gemm_ring_kernel, split-K form (the LM-head dgrad): the bias value is loaded and settled ONCE in front of the atomics.
+    With the load next to its use every global_atomic_add_f32 sat behind its own s_waitcnt vmcnt(0), i.e. behind the completion
+    of all atomics before it."""
+    ks = {k: v for k, v in _kernels(_asm("ns_gemm_ring.hip", tmp_path)).items() if "ns_gemm_ring_kernel" in k}
+    assert len(ks) == 4
+    for name, body in ks.items():
+        lines = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
+        n_at = sum(1 for l in lines if l.startswith("global_atomic_add_f32"))
+        assert n_at >= 32, (name, n_at)
+        waited = 0
+        for i, l in enumerate(lines):
+            if l.startswith("global_atomic_add_f32") and any(x.startswith("s_waitcnt vmcnt(0)") for x in lines[max(0, i - 3):i]):
+                waited += 1
+        assert waited <= 2, (name, waited, n_at)
