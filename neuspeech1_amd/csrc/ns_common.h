@@ -101,12 +101,18 @@ __device__ __forceinline__ float ns_gelu_grad(float x) {
 // the weight-gradient staging: one 32-bit hash per group of 4 consecutive columns, one byte per element, keep iff
 // byte >= thr8.  The drop probability is therefore quantised to thr8/256 (0.05 -> 13/256 = 0.0508) and the
 // survivors are scaled by 1/(1 - thr8/256).
-__device__ __forceinline__ uint32_t ns_hash3(uint32_t seed, uint32_t a, uint32_t b) {
-  uint32_t x = seed ^ (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u);
+// (the two input products are linear mod 2^32: a caller that walks rows / column groups by constant steps forms a * NS_HASH_A and
+//  b * NS_HASH_B once and adds constants -- 32-bit integer multiplies are quarter-rate VALU operations)
+#define NS_HASH_A 0x9E3779B1u
+#define NS_HASH_B 0x85EBCA77u
+__device__ __forceinline__ uint32_t ns_hash3_mix(uint32_t x) {      // x = seed ^ a * NS_HASH_A ^ b * NS_HASH_B
   x ^= x >> 16; x *= 0x7FEB352Du;
   x ^= x >> 15; x *= 0x846CA68Bu;
   x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t ns_hash3(uint32_t seed, uint32_t a, uint32_t b) {
+  return ns_hash3_mix(seed ^ (a * NS_HASH_A) ^ (b * NS_HASH_B));
 }
 // effective dropout seed of a launch: ns_gemm_desc.seed_dev (a device-resident step counter, wave-uniform scalar load) folded in
 __device__ __forceinline__ uint32_t ns_eff_seed(uint32_t seed, const uint32_t* seed_dev) {

@@ -55,6 +55,37 @@ __device__ __forceinline__ uint32_t rm_off32(const ns_rowmap& m, int row) {
   }
   return (uint32_t)row * (uint32_t)m.ld;
 }
+// Element offsets of the tile rows row0 + c (0 <= c < 256, c a compile-time constant) of a row map WITHOUT a multiply or a division
+// per row: rm_off32 per row and output was two quarter-rate v_mul_lo_u32 for a plain map and a 35-instruction integer division for a
+// segmented one (the conv stem's halo layouts) -- a quarter of a GELU epilogue row on the conv launches (round 4, ISA).  `base` is the
+// offset of row0; c * ld is a scalar product; a tile crosses at most four segment ends (seg_rows >= 64), each adds `jump`.
+struct rm_walk {
+  uint32_t base, w0, jump;
+  int seg_rows, ld;
+  __device__ __forceinline__ void init(const ns_rowmap& m, int row0) {
+    ld = m.ld;
+    seg_rows = m.seg_rows;
+    if (m.seg_rows > 0) {
+      const int s = row0 / m.seg_rows;
+      w0 = (uint32_t)(row0 - s * m.seg_rows);
+      base = (uint32_t)s * (uint32_t)m.seg_stride + w0 * (uint32_t)m.ld;
+      jump = (uint32_t)m.seg_stride - (uint32_t)m.seg_rows * (uint32_t)m.ld;
+    } else {
+      w0 = 0u;
+      base = (uint32_t)row0 * (uint32_t)m.ld;
+      jump = 0u;
+    }
+  }
+  __device__ __forceinline__ uint32_t at(int c) const {
+    uint32_t o = base + (uint32_t)(c * ld);
+    if (seg_rows > 0) {
+      const uint32_t w = w0 + (uint32_t)c;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) o += w >= (uint32_t)(k * seg_rows) ? jump : 0u;
+    }
+    return o;
+  }
+};
 template <class T>
 __device__ __forceinline__ T ld32(const void* base, uint32_t byte_off) { return *(const T*)((const char*)base + byte_off); }
 template <class T>
@@ -428,17 +459,22 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
       for (int nt = 0; nt < 2; ++nt) {
         bz[bh][nt] = *(const float4*)(smem + BIAS_OFF + par * 2048 + (wn * 64 + bh * 32 + nt * 16 + 4 * lge) * 4);
       }
+    // this thread's rows of half hh: staged row er0 + 16 i (er0 < 16) = tile row hh * 64 + er0 + rowc(i), rowc(i) = (i >> 2) * 128 + 16 * (i & 3)
+    // a compile-time constant: offsets walk from the first row's (rm_walk) instead of being re-derived row by row
+    auto rowc = [](int i) __attribute__((always_inline)) { return (i >> 2) * 128 + 16 * (i & 3); };
     auto grow = [&](int hh, int rl) __attribute__((always_inline)) { return m0 + ((rl >> 6) << 7) + hh * 64 + (rl & 63); };
     auto prefetch = [&](int hh) __attribute__((always_inline)) {
+      const int row0 = m0 + hh * 64 + er0;
+      rm_walk wk;
+      wk.init(KIND == NS_EPI_RES ? h32m : p16m, min(row0, p.M - 1));
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int row = min(grow(hh, er0 + 16 * i), p.M - 1);
+        const uint32_t o = row0 + rowc(i) < p.M ? wk.at(rowc(i)) : 0u;      // rows past M: any valid address (never consumed)
         if (KIND == NS_EPI_RES) {
-          const uint32_t oh = rm_off32(h32m, row);
-          res[i][0] = p.R32 ? ld32<f32x4>(p.R32, 4u * (oh + (uint32_t)rcolAc)) : f32x4{0.f, 0.f, 0.f, 0.f};
-          res[i][1] = p.R32 ? ld32<f32x4>(p.R32, 4u * (oh + (uint32_t)rcolBc)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          res[i][0] = p.R32 ? ld32<f32x4>(p.R32, 4u * (o + (uint32_t)rcolAc)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          res[i][1] = p.R32 ? ld32<f32x4>(p.R32, 4u * (o + (uint32_t)rcolBc)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (KIND == NS_EPI_DGELU) pre[hh * 8 + i] = ld32<half8>(P16, 2u * (rm_off32(p16m, row) + (uint32_t)ecolc));
+        if (KIND == NS_EPI_DGELU) pre[hh * 8 + i] = ld32<half8>(P16, 2u * (o + (uint32_t)ecolc));
       }
     };
     // half 0 carries the next tile's first K tile (-> ring buffer 0, dead since the main loop ended) and its bias values: one piece after
@@ -475,6 +511,14 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           vst[i] = *(const half8*)(hs + (er0 + 16 * i) * LDH + ecg * 16);
         }
       }
+      // offsets of this thread's first row of the half in every destination, walked row by row below
+      const int frow0 = m0 + hh * 64 + er0;
+      rm_walk wc, wg, wh;
+      if (C16) wc.init(c16m, min(frow0, p.M - 1));
+      if (G16) wg.init(g16m, min(frow0, p.M - 1));
+      if (KIND == NS_EPI_RES) wh.init(h32m, min(frow0, p.M - 1));
+      const uint32_t side_ha0 = (uint32_t)frow0 * NS_HASH_A;
+      const uint32_t side_hb0 = side_dseed ^ (((uint32_t)ecol >> 2) * NS_HASH_B), side_hb1 = side_dseed ^ ((((uint32_t)ecol >> 2) + 1) * NS_HASH_B);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         {
@@ -484,7 +528,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           if (KIND != NS_EPI_RES && do_gelu) {
             if ((i & 1) == wm) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
           }
-          const int rl = er0 + 16 * i, row = grow(hh, rl);
+          const int rl = er0 + 16 * i, row = frow0 + rowc(i);
           if (!(KIND == NS_EPI_RES ? rokA : ecolok) || row >= p.M) continue;
           half8 v = vst[i];
           if (KIND == NS_EPI_DGELU) {
@@ -514,8 +558,10 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
             uint4 w = __builtin_bit_cast(uint4, gv);
             if (side_thr) {
               uint32_t mk[4];
-              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, (uint32_t)ecol >> 2), side_thr, mk[0], mk[1]);
-              ns_keep_masks(ns_drop_word(side_dseed, (uint32_t)row, ((uint32_t)ecol >> 2) + 1), side_thr, mk[2], mk[3]);
+              // ns_drop_word(seed, row, col4) with its two input products walked instead of multiplied (ns_common.h)
+              const uint32_t ha = side_ha0 + (uint32_t)rowc(i) * NS_HASH_A;
+              ns_keep_masks(ns_hash3_mix(side_hb0 ^ ha), side_thr, mk[0], mk[1]);
+              ns_keep_masks(ns_hash3_mix(side_hb1 ^ ha), side_thr, mk[2], mk[3]);
               w.x &= mk[0]; w.y &= mk[1]; w.z &= mk[2]; w.w &= mk[3];
             }
             // an asm store: behind a C++ store to LDS hipcc waits vmcnt(0) for the next tile's LDS-DMA pieces in flight (it models them as LDS
@@ -525,24 +571,24 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           }
           if (KIND == NS_EPI_RES) {
             if (C16) {
-              const uint32_t oc = rm_off32(c16m, row);
+              const uint32_t oc = wc.at(rowc(i));
               st32<half4>(C16, 2u * (oc + (uint32_t)rcolA), half4{cv[0], cv[1], cv[2], cv[3]});
               if (rokB) st32<half4>(C16, 2u * (oc + (uint32_t)rcolB), half4{cv[4], cv[5], cv[6], cv[7]});
             }
             if (G16) {
-              const uint32_t og = rm_off32(g16m, row);
+              const uint32_t og = wg.at(rowc(i));
               st32<half4>(G16, 2u * (og + (uint32_t)rcolA), half4{gv[0], gv[1], gv[2], gv[3]});
               if (rokB) st32<half4>(G16, 2u * (og + (uint32_t)rcolB), half4{gv[4], gv[5], gv[6], gv[7]});
             }
           } else {
-            if (C16) st32<half8>(C16, 2u * (rm_off32(c16m, row) + (uint32_t)ecol), cv);
-            if (G16) st32<half8>(G16, 2u * (rm_off32(g16m, row) + (uint32_t)ecol), gv);
+            if (C16) st32<half8>(C16, 2u * (wc.at(rowc(i)) + (uint32_t)ecol), cv);
+            if (G16) st32<half8>(G16, 2u * (wg.at(rowc(i)) + (uint32_t)ecol), gv);
           }
           if (KIND == NS_EPI_RES) {
             f32x4 h0 = res[i][0], h1 = res[i][1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { h0[e] += (float)gv[e]; h1[e] += (float)gv[4 + e]; }
-            const uint32_t oh = rm_off32(h32m, row);
+            const uint32_t oh = wh.at(rowc(i));
             st32<f32x4>(p.H32, 4u * (oh + (uint32_t)rcolA), h0);
             if (rokB) st32<f32x4>(p.H32, 4u * (oh + (uint32_t)rcolB), h1);
           }
