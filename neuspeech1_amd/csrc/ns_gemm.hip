@@ -500,8 +500,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
     // the persistent form (one workgroup per CU walks its tiles, epilogue / next-prologue overlap) where its 32-bit epilogue addressing
     // applies and a CU gets four or more tiles (below that the one-tile form with its dynamic tile order is as fast or faster); mode 4 forces the one-tile-per-workgroup form (A/B runs)
-    if (big && p8_ok && g_use_ring == 1 && tiles256 >= 1024 && !(d->flags & (1 << 27)) && ns_gemm_p8s_ok(d)) ns_gemm_p8s_launch(d, st);
-    else if (big && p8_ok && g_use_ring == 9 && ns_gemm_p8s_ok(d)) ns_gemm_p8s_launch(d, st);
+    const bool pers = big && p8_ok && ((g_use_ring == 1 && tiles256 >= 1024 && !(d->flags & (1 << 27))) || g_use_ring == 9) && ns_gemm_p8s_ok(d);
+    if (pers) ns_gemm_p8s_launch(d, st);
     else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) ns_gemm_p8_launch(d, st);
     else {
       // only ns_gemm_p8_kernel forms the side product: any other kernel would leave side_out unwritten and the caller's
