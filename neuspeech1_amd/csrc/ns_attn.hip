@@ -103,10 +103,11 @@ __device__ __forceinline__ void xcd_block_ids(int& bx, int& by, int& bz) {
 // =============================================================== forward
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_attn_desc p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
-  char* const Ks = smem;
-  char* const Vs = smem + 8192;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  // two K / V tile pairs: tile t + 1 travels from global memory straight into its LDS image (buffer_load ... lds, 1 KiB per piece of eight
+  // rows, four pieces per wave and tile) while tile t is consumed -- ONE barrier per tile.  (Round 3: one tile pair, staged through 16
+  // registers per thread with two barriers per tile.)
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
   int bx_, h, b;
   xcd_block_ids(bx_, h, b);
   const int q0 = bx_ * 128;
@@ -117,15 +118,39 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
   const int qrow = min(qi, p.Lq - 1);
   const int coff = p.Lk - p.Lq;                   // causal: key j visible iff j <= qi + coff
 
+  int kend = p.Lk;
+  if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);  // keys beyond the block's last query are never visible
+  const int ntiles = (max(kend, 0) + 63) / 64;
+
+  // tile transport (inline assembly: behind the builtin hipcc orders every LDS read after the pieces it knows to be in flight, an
+  // s_waitcnt vmcnt(0) per tile in the wrong place; see ns_attn_bwd1.hip).  Lane l of a piece holds row 8 piece + ((l >> 2) & 7), chunk
+  // 4 (l >> 5) + ((l & 3) ^ swizzle(row)): byte 16 l of the image's 1-KiB unit.  Keys past Lk repeat row Lk - 1 (masked below).
+  const ns_u4v rsrc_k = {(uint32_t)(uintptr_t)K, (uint32_t)((uintptr_t)K >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
+  const ns_u4v rsrc_v = {(uint32_t)(uintptr_t)V, (uint32_t)((uintptr_t)V >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  auto dma_tile = [&](int buf, int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = 2 * wave + j;
+      const int row = 8 * piece + ((lane >> 2) & 7);
+      const int chunk = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));
+      const uint32_t kr = (uint32_t)min(k0 + row, p.Lk - 1);
+      const uint32_t dst = smem_base + (uint32_t)(buf * 16384 + piece * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(2u * (kr * (uint32_t)p.ldk + chunk * 8)), "s"(rsrc_k) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst + 8192u), "v"(2u * (kr * (uint32_t)p.ldv + chunk * 8)), "s"(rsrc_v) : "memory");
+    }
+  };
+  if (ntiles > 0) dma_tile(0, 0);
+
   // Global rows as 128-B segments through LDS, never as per-lane fragment pieces (lane = row: 32 rows x 32 B per load instruction, 16 B per
   // row and store instruction -- the CU retires such pieces at its request rate, well below HBM's): this wave's 32 query rows go through
-  // its own 4 KiB of the (still idle) K / V tile buffers, and O leaves the same way.
+  // its own 4 KiB of the second (still idle) tile pair, and O leaves the same way.
   half8 qf[4];
   (void)qrow;
   {
     const int l16 = lane & 15;
     const int srow = 2 * (lane >> 4) + ((l16 >> 2) & 1), schunk = (l16 & 3) + 4 * (l16 >> 3);   // + 8 i rows: see rm_lane
-    char* const wst = smem + wave * 4096;
+    char* const wst = smem + 16384 + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int qr = min(q0 + wave * 32 + 8 * i + srow, p.Lq - 1);
@@ -142,19 +167,15 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
     for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  int kend = p.Lk;
-  if (CAUSAL) kend = min(p.Lk, q0 + 128 + coff);  // keys beyond the block's last query are never visible
-  const int ntiles = (max(kend, 0) + 63) / 64;
-
-  uint4 kr0, kr1, vr0, vr1;
-  if (ntiles > 0) { load_rm(K, p.ldk, 0, p.Lk, kr0, kr1); load_rm(V, p.ldv, 0, p.Lk, vr0, vr1); }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * 64;
-    __syncthreads();
-    store_rm(Ks, kr0, kr1);
-    store_rm(Vs, vr0, vr1);
-    __syncthreads();
-    if (t + 1 < ntiles) { load_rm(K, p.ldk, k0 + 64, p.Lk, kr0, kr1); load_rm(V, p.ldv, k0 + 64, p.Lk, vr0, vr1); }
+    const char* const Ks = smem + (t & 1) * 16384;
+    const char* const Vs = Ks + 8192;
+    // this wave's pieces of tile t are in; behind the barrier everyone's are, and every wave is through tile t - 1 (the other pair is free)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) dma_tile((t + 1) & 1, k0 + 64);
 
     f32x16 st[2];
 #pragma unroll
