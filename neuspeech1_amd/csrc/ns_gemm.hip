@@ -365,6 +365,12 @@ int ns_gemm_tn256_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_tn256_ok(const ns_gemm_desc* d);
 int ns_gemm_skinny_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
+// the persistent form from this many 256 x 256 tiles on (A/B builds: -DNS_P8S_MIN_TILES=...).  1024 until round 4; with that round's epilogues the
+// 750-tile launches (N = 512 at M = 96 000: the fp32-residual out-projection / fc2 and the K <= 2048 dgrads) gain too: 31.52 - 31.56 against
+// 31.66 - 31.75 ms per step, same box
+#ifndef NS_P8S_MIN_TILES
+#define NS_P8S_MIN_TILES 700
+#endif
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
 
@@ -499,8 +505,8 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);
     // the persistent form (one workgroup per CU walks its tiles, epilogue / next-prologue overlap) where its 32-bit epilogue addressing
-    // applies and a CU gets four or more tiles (below that the one-tile form with its dynamic tile order is as fast or faster); mode 4 forces the one-tile-per-workgroup form (A/B runs)
-    const bool pers = big && p8_ok && ((g_use_ring == 1 && tiles256 >= 1024 && !(d->flags & (1 << 27))) || g_use_ring == 9) && ns_gemm_p8s_ok(d);
+    // applies and a CU gets about three or more tiles (NS_P8S_MIN_TILES; below that the one-tile form with its dynamic tile order is as fast or faster); mode 4 forces the one-tile-per-workgroup form (A/B runs)
+    const bool pers = big && p8_ok && ((g_use_ring == 1 && tiles256 >= NS_P8S_MIN_TILES && !(d->flags & (1 << 27))) || g_use_ring == 9) && ns_gemm_p8s_ok(d);
     if (pers) ns_gemm_p8s_launch(d, st);
     else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) ns_gemm_p8_launch(d, st);
     else {

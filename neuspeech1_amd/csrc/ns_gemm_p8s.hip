@@ -16,7 +16,7 @@
 //     epilogue is a VMEM operation that waits for every store before it.  Epilogue accesses are scalar base + 32-bit offset.
 //   * No position-row add (the conv2 epilogue stays on ns_gemm_p8_kernel), destinations below 4 GiB (ns_gemm_p8s_ok).
 // Tiles of one XCD's range are dealt round-robin to that XCD's workgroups (same L2 sharing as the one-tile-per-workgroup map).
-// ns_gemm dispatches here at >= 1024 tiles (four or more per CU); below that the one-tile form, whose tiles the hardware deals dynamically,
+// ns_gemm dispatches here at >= 700 tiles (NS_P8S_MIN_TILES in ns_gemm.hip: about three or more per CU); below that the one-tile form, whose tiles the hardware deals dynamically,
 // is as fast or faster (same-box A/B of whole steps: 32.7 ms against 33.3 with the one-tile form everywhere and 33.6 with this one everywhere).
 #include "ns_gemm_epi.h"
 #include <mutex>

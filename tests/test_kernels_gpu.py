@@ -964,7 +964,7 @@ def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
 
 
 def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
-    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 1024 tiles) against ns_gemm_p8 (one tile per
+    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 700 tiles) against ns_gemm_p8 (one tile per
     workgroup) on ragged shapes with > 256 tiles, so that workgroups really carry the next tile's prologue through an epilogue:
     every epilogue kind, second product (ragged column groups, LoRA dropout), segmented row maps with an in-place residual, the
     GELU side product.  Same arithmetic in the same order: outputs must be bit-identical."""
