@@ -136,8 +136,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
       const int chunk = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));
       const uint32_t kr = (uint32_t)min(k0 + row, p.Lk - 1);
       const uint32_t dst = smem_base + (uint32_t)(buf * 16384 + piece * 1024);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(2u * (kr * (uint32_t)p.ldk + chunk * 8)), "s"(rsrc_k) : "memory");
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst + 8192u), "v"(2u * (kr * (uint32_t)p.ldv + chunk * 8)), "s"(rsrc_v) : "memory");
+      // (m0 saved and restored around the transfers: a reserved register cannot be named as a clobber)
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, 0 offen lds\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "s"(dst), "s"(dst + 8192u), "v"(2u * (kr * (uint32_t)p.ldk + chunk * 8)), "v"(2u * (kr * (uint32_t)p.ldv + chunk * 8)), "s"(rsrc_k), "s"(rsrc_v)
+                   : "memory");
     }
   };
   if (ntiles > 0) dma_tile(0, 0);

@@ -211,7 +211,11 @@ __device__ __forceinline__ void sweep(const ns_attn_desc& p, char* smem, float* 
   const ns_u4v rsrc_o = {(uint32_t)(uintptr_t)Oin, (uint32_t)((uintptr_t)Oin >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
   const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_void*)smem;
   auto dma16 = [&](const ns_u4v& rsrc, uint32_t lds_byte, uint32_t voff) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+    // (m0 is saved and restored around the transfer, as in ns_gemm_tn256.hip: the register is reserved -- it cannot be named as a clobber -- and
+    // hipcc may keep a value of its own in it)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
   };
   // lane l of a piece holds row 8 w + ((l >> 2) & 7), chunk 4 (l >> 5) + ((l & 3) ^ swizzle(row)): byte 16 l of the unit in lds_off's layout
   const int prow_l = 8 * wave + ((lane >> 2) & 7);
