@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from neuspeech1_amd.peft_compat import PeftModel
-from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding
+from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, fork_safe_iter
 from utils.load_model import WhisperForConditionalGeneration
 from utils.model_utils import projection_module
 from utils.reader import CustomDataset, write_jsonlines
@@ -117,7 +117,7 @@ def main(argv=None):
         # chance baseline of the reference (:330-331, :406-420, :462-466): every prediction is a label drawn at random
         # from the test list itself; the model is not run
         all_labels = []
-        for batch in loader:
+        for batch in fork_safe_iter(loader):
             lab = np.where(batch["labels"].numpy() != -100, batch["labels"].numpy(), processor.tokenizer.pad_token_id)
             all_labels.extend(processor.batch_decode(lab, skip_special_tokens=True))
         all_preds = np.random.choice(all_labels, len(all_labels)).tolist()
@@ -137,7 +137,7 @@ def main(argv=None):
 
     def batches():
         """(input, labels) with the NEXT batch's file reads already running on the feed's loader thread"""
-        it = iter(loader)
+        it = fork_safe_iter(loader)
         stage = lambda b: feed.submit(b["input_features"]) if (feed is not None and b is not None) else None  # noqa: E731
         nxt = next(it, None)
         fut = stage(nxt)
@@ -199,6 +199,8 @@ def main(argv=None):
                 f.write(f"Predicted: {p}\nTrue: {l}\n")
                 f.write("end==================================\n\n")
     dt = time.time() - t0
+    if feed is not None:
+        feed.close()        # its loader / reader threads end here, not whenever the collector finds the feed
     if world > 1:
         parts = [None] * world
         dist.all_gather_object(parts, (preds, refs, n_new, n_match, n_lab, dt, t_gen))

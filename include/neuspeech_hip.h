@@ -169,7 +169,7 @@ int ns_layernorm_fwd_lora(const float* x, const float* gamma, const float* beta,
 /* ------------------------------------------------------------------------
  * ns_signal_pack: the MEG batch (B, ch, T) fp32 exactly as the collator emits
  * it (utils/data_utils.py:191-193) -> (B, T+2, Cp) fp16 token-major with zero
- * halo rows 0 and T+1 and zero channels [ch, Cp); Cp % 64 == 0.  This is the
+ * halo rows 0 and T+1 and zero channels [ch, Cp); Cp % 8 == 0.  This is the
  * only full-size read of the signal tensor (coalesced along T).
  * ---------------------------------------------------------------------- */
 int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream);

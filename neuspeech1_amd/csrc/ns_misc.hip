@@ -66,10 +66,11 @@ __global__ __launch_bounds__(256) void signal_pack_kernel(const float* __restric
   for (int it = 0; it < 2; ++it) {
     const int tl = (threadIdx.x >> 3) + 32 * it;
     const int t = t0 + tl;
-    if (t < T) *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = *(const half8*)(tile + tl * 128 + (((cc >> 3) ^ ((tl >> 2) & 7)) << 4));
+    // (Cp is a multiple of 8, not of the tile's 64: the last channel block writes only its pieces below Cp)
+    if (t < T && c0 + cc < Cp) *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = *(const half8*)(tile + tl * 128 + (((cc >> 3) ^ ((tl >> 2) & 7)) << 4));
   }
   // halo rows
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (blockIdx.x == 0 && threadIdx.x < 64 && c0 + (int)threadIdx.x < Cp) {
     ob[c0 + threadIdx.x] = (half_t)0.f;
     ob[(size_t)(T + 1) * Cp + c0 + threadIdx.x] = (half_t)0.f;
   }
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(256) void feed_pack_kernel(const ns_feed_item* __re
   for (int k = 0; k < 2; ++k) {
     const int tl = (threadIdx.x >> 3) + 32 * k;
     const int t = t0 + tl;
-    if (t < T) {
+    if (t < T && c0 + cc < Cp) {
       half8 h;
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[e] = tile[cc + e][tl];
       *(half8*)(ob + (size_t)(t + 1) * Cp + c0 + cc) = h;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (blockIdx.x == 0 && threadIdx.x < 64 && c0 + (int)threadIdx.x < Cp) {
     ob[c0 + threadIdx.x] = (half_t)0.f;
     ob[(size_t)(T + 1) * Cp + c0 + threadIdx.x] = (half_t)0.f;
   }
@@ -395,8 +396,8 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
 
 extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream) {
   NS_CHECK_ARG(x && out16, "ns_signal_pack: null pointer");
-  NS_CHECK_ARG(B > 0 && ch > 0 && T > 0 && Cp >= ch && Cp % 64 == 0, "ns_signal_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
-  dim3 grid((T + 63) / 64, Cp / 64, B);
+  NS_CHECK_ARG(B > 0 && ch > 0 && T > 0 && Cp >= ch && Cp % 8 == 0, "ns_signal_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
+  dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   if (T % 4 == 0 && ((uintptr_t)x & 15) == 0)
     hipLaunchKernelGGL(signal_pack_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (half_t*)out16, ch, T, Cp);
   else
@@ -408,9 +409,9 @@ extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T,
 extern "C" int ns_feed_pack(const ns_feed_item* items_dev, int B, int ch, int T, int Cp, void* out16, float* x32,
                             void* stream) {
   NS_CHECK_ARG(items_dev && out16, "ns_feed_pack: null pointer");
-  NS_CHECK_ARG(B > 0 && B <= 65535 && ch > 0 && T > 0 && Cp >= ch && Cp % 64 == 0,
+  NS_CHECK_ARG(B > 0 && B <= 65535 && ch > 0 && T > 0 && Cp >= ch && Cp % 8 == 0,
                "ns_feed_pack: bad shape B=%d ch=%d T=%d Cp=%d", B, ch, T, Cp);
-  dim3 grid((T + 63) / 64, Cp / 64, B);
+  dim3 grid((T + 63) / 64, (Cp + 63) / 64, B);
   hipLaunchKernelGGL(feed_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, items_dev, (half_t*)out16, x32, ch, T, Cp);
   NS_CHECK_LAUNCH("ns_feed_pack");
   return NS_OK;

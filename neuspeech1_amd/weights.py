@@ -38,7 +38,10 @@ class WhisperDims:
 
     @property
     def ch_pad(self) -> int:
-        return (self.ch + 63) // 64 * 64
+        """channels of the packed (B, T + 2, Cp) signal image: the next multiple of 16 (the first conv's K = 3 Cp has to be a multiple of 16 for
+        the NT GEMM).  Rounds 1-3 padded to 64 -- K = 768 for the algorithmic 624 of the 208-channel first conv (now 624), 960 for 819 at 273
+        channels (now 864)"""
+        return max(48, (self.ch + 15) // 16 * 16)     # (48: the first conv's weight-gradient kernel wants 3 Cp > 96 -- toy configs only)
 
     @property
     def vocab_pad(self) -> int:

@@ -485,7 +485,7 @@ def test_adalora_matches_reference_on_merged_weights(dev):
 
 @pytest.mark.parametrize("tag", ["base273", "lv2w"])
 def test_273_channels_and_large_v2_width_match_reference_golden(dev, tag):
-    """BASELINE configs[3] shape (whisper-base, 273 channels: ch_pad 320, first conv K = 960; /root/reference
+    """BASELINE configs[3] shape (whisper-base, 273 channels: ch_pad 288, first conv K = 864; /root/reference
     README.md:60-64) and configs[4]'s WIDTH (d 1280, 20 heads, ffn 5120; 2 + 2 layers), B = 1: loss, encoder states,
     logits and the conv-stem gradients against the reference object (tests/golden/train_{base273,lv2w}.npz)."""
     from neuspeech1_amd.weights import LV2W, WhisperDims

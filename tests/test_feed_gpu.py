@@ -22,7 +22,7 @@ def test_feed_pack_is_bit_identical_to_collator_plus_signal_pack(dev, tmp_path, 
     coll = DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
     ref = coll([ds[i] for i in range(len(ds))])
     raws = coll([ds_raw[i] for i in range(len(ds_raw))])["input_features"]
-    B, T, Cp = len(raws), 6000, (modal_ch + 63) // 64 * 64
+    B, T, Cp = len(raws), 6000, (modal_ch + 15) // 16 * 16
     x32 = ref["input_features"].to(dev)
     want = torch.full((B, T + 2, Cp), 7.0, dtype=torch.float16, device=dev)
     ops.signal_pack(x32, want, B, modal_ch, T, Cp)

@@ -357,10 +357,12 @@ def test_layernorm_fused_with_lora_down_projection(ops, dev, rows, d, n_out, p):
 
 
 # --------------------------------------------------------------------------- byte movers
+@pytest.mark.parametrize("pad", [8, 64])
 @pytest.mark.parametrize("ch,T", [(208, 6000), (273, 6000), (10, 100), (20, 402), (70, 130)])
-def test_signal_pack(ops, dev, ch, T):
+def test_signal_pack(ops, dev, ch, T, pad):
+    """Cp = the next multiple of 8 (what WhisperDims.ch_pad gives: the last 64-channel block of the kernel's grid is partial) and of 64"""
     Bn = 2
-    Cp = (ch + 63) // 64 * 64
+    Cp = (ch + pad - 1) // pad * pad
     x = rnd((Bn, ch, T), dev, 0.35, torch.float32, seed=1).clamp(-1, 1)
     out = torch.full((Bn, T + 2, Cp), float("nan"), device=dev, dtype=torch.float16)
     ops.signal_pack(x, out, Bn, ch, T, Cp)

@@ -5,6 +5,8 @@ import string
 from dataclasses import dataclass
 from typing import Any, Dict, List, Union
 
+import gc
+
 import numpy as np
 import torch
 
@@ -79,3 +81,23 @@ class DataCollatorSpeechSeq2SeqWithPadding:
 
 # the reference's speech-only collator is the same object (reference :150-178)
 DataCollatorOnlySpeechSeq2SeqWithPadding = DataCollatorSpeechSeq2SeqWithPadding
+
+
+def fork_safe_iter(loader):
+    """iter(loader) for a DataLoader whose workers are FORKED from a process that holds HIP objects.
+
+    A forked child must not run a HIP call.  The workers' own code does not -- but their cyclic garbage collector may: garbage the parent
+    has not collected yet (a closed feed's staging slots with their events and streams, a finished generator's graph objects) is garbage
+    in the child too, and the first collection there runs the destructors, i.e. hipEventDestroy / hipStreamDestroy in a forked process:
+    a segmentation fault in a DataLoader worker, depending on allocation counts (seen in round 4 when a shape change moved the collector's
+    threshold).  Collect in the parent first, then freeze what is left for the duration of the fork (gc.freeze() exists for this: the
+    children inherit the frozen generation and never look at it)."""
+    if getattr(loader, "num_workers", 0) > 0:
+        gc.collect()
+        gc.freeze()
+        try:
+            return iter(loader)      # _MultiProcessingDataLoaderIter starts (forks) its workers here
+        finally:
+            gc.unfreeze()
+    return iter(loader)
+
