@@ -399,6 +399,8 @@ def main(argv=None):
                 break
         if done:
             break
+    if feed is not None:
+        feed.close()        # its loader / reader threads end here, not whenever the collector finds the feed
     if rank == 0:
         model.save_pretrained(os.path.join(output_dir, "checkpoint-final"))
         print(f"saved {os.path.join(output_dir, 'checkpoint-final')}")
