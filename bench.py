@@ -31,7 +31,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 # tiles, the position-row epilogue) and persistent (ns_gemm_p8s_kernel: >= 1024 tiles) -- one tile arithmetic, one "nt256" class in the
 # event-timed leg; in the rocprof stats its average launch = all ns_gemm_p8*_kernel rows together
 DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
-PMC_FILE = "profiles/r4_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
+PMC_FILE = "profiles/r5_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 DECODE_PMC_FILE = "profiles/r4_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
 LV2_GFLOP_PER_SAMPLE = 5630.0   # whisper-large-v2, 273-ch, fwd+bwd
 
@@ -244,10 +244,10 @@ def eval_tokens_per_s(dev):
     return out
 
 
-def large_v2_leg(dev, B=32, steps=3):
+def large_v2_leg(dev, B=64, steps=3):
     """BASELINE configs[4] on the one GPU of this run: whisper-large-v2 (32 + 32 layers, d 1280), 273-ch, fp16 LoRA r = 32
-    (dropout 0.05) + conv-stem training step, B = 32 (B = 64 fits too: 169 GB): 1 warm-up (eager) + 1 capture + `steps`
-    timed graph replays.  Reported beside the headline, never as `value`."""
+    (dropout 0.05) + conv-stem training step at SURVEY 8(d)'s B = 64 per GPU (169 GB of the 288 GB; rounds 1-4 ran B = 32):
+    1 warm-up (eager) + 1 capture + `steps` timed graph replays.  Reported beside the headline, never as `value`."""
     import torch
     from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
     from neuspeech1_amd.weights import WHISPER_LARGE_V2, make_state_dict, synth_batch

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from neuspeech1_amd.peft_compat import PeftModel
-from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, fork_safe_iter
+from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, fork_safe_iter, start_worker_server, worker_context
 from utils.load_model import WhisperForConditionalGeneration
 from utils.model_utils import projection_module
 from utils.reader import CustomDataset, write_jsonlines
@@ -63,6 +63,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.num_workers > 0:
+        start_worker_server()       # the DataLoader workers' forkserver: a fresh helper process, started before anything touches the GPU
     print_arguments(args)
     assert args.model_path.startswith("synthetic:") or os.path.exists(args.model_path), f"model {args.model_path} not found"
     from finetune import get_processor
@@ -107,7 +109,8 @@ def main(argv=None):
     print(f"test samples: {len(test_dataset)}")
     collator = DataCollatorSpeechSeq2SeqWithPadding(processor=processor)
     shard = test_dataset if world == 1 else torch.utils.data.Subset(test_dataset, list(range(rank, len(test_dataset), world)))
-    loader = torch.utils.data.DataLoader(shard, batch_size=args.batch_size, num_workers=args.num_workers, collate_fn=collator)
+    loader = torch.utils.data.DataLoader(shard, batch_size=args.batch_size, num_workers=args.num_workers, collate_fn=collator,
+                                         multiprocessing_context=worker_context(args.num_workers))
     base = (f'formal_test_results{"_" + args.extra_name if args.extra_name is not None else ""}'
             f'{"no_post_processing" if not args.post_processing else "post_processing"}'
             f'{"_noise" if args.noise else ""}{"_randomChoice" if args.random_choice else ""}'

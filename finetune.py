@@ -23,7 +23,8 @@ import torch
 from neuspeech1_amd.dp import GradReducer
 from neuspeech1_amd.engine import TrainCfg
 from neuspeech1_amd.peft_compat import AdaLoraConfig, LoraConfig, PeftModel, get_peft_model, prepare_model_for_kbit_training
-from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, fork_safe_iter, get_part_of_dataset
+from utils.data_utils import (DataCollatorSpeechSeq2SeqWithPadding, fork_safe_iter, get_part_of_dataset, start_worker_server,
+                              worker_context)
 from utils.load_model import WhisperForConditionalGeneration, match_modules, match_modules_string
 from utils.model_utils import projection_module
 from utils.reader import CustomDataset
@@ -211,6 +212,8 @@ def rotate_checkpoints(output_dir, keep):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.num_workers > 0:
+        start_worker_server()       # the DataLoader workers' forkserver: a fresh helper process, started before anything touches the GPU
     print_arguments(args)
     if args.gradient_accumulation_steps < 1:
         raise ValueError("gradient_accumulation_steps must be >= 1")
@@ -336,7 +339,8 @@ def main(argv=None):
     sampler = EpochShardSampler(len(train_dataset), rank, world)
     loader = torch.utils.data.DataLoader(train_dataset, batch_size=B, sampler=sampler, num_workers=args.num_workers,
                                          collate_fn=data_collator, drop_last=False, pin_memory=True,
-                                         persistent_workers=args.num_workers > 0)
+                                         persistent_workers=args.num_workers > 0,
+                                         multiprocessing_context=worker_context(args.num_workers))
     n_batches = len(loader)
     rk = dict(on_ready=reducer.on_ready, reduce_fn=reducer.finish) if reducer is not None else {}
     for epoch in range(args.num_train_epochs):

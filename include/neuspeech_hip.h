@@ -35,7 +35,7 @@ typedef enum {
   NS_ERR_HIP = -3
 } ns_status;
 
-int ns_version(void);                 /* ABI version, currently 2 (bumped with every descriptor-layout / signature change) */
+int ns_version(void);                 /* ABI version, currently 3 (bumped with every descriptor-layout / signature change) */
 const char* ns_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------
@@ -211,6 +211,17 @@ int ns_embed_pos(const int64_t* ids, const float* E32, const float* P32, float* 
 int ns_dgelu_mul(const void* a16, const void* pre16, void* out16, const ns_rowmap* out_map, int rows, int cols,
                  int pre_is_grad, void* stream);
 int ns_colsum(const void* a16, float* out32, int rows, int cols, int ld, float alpha, void* stream);
+
+/* Buffer clears and the step counter of a captured training step as KERNELS: the step (finetune.py:231-253,281 as the HF
+ * Trainer runs it: zero_grad, forward, backward, optimizer) is replayed from hipGraphs, and a captured memset NODE was not
+ * reliably ordered against the kernel nodes around it under back-to-back replays (see ns_orth_reg).  ns_zero_spans clears
+ * up to NS_ZERO_MAX_SPANS buffers in one launch (`spans` is a HOST array, copied into the launch arguments; each span
+ * 16-byte aligned, a multiple of 4 bytes); ns_add_i32 advances a device counter (the LoRA-dropout step counter that
+ * ns_gemm_desc.seed_dev points at). */
+#define NS_ZERO_MAX_SPANS 8
+typedef struct { void* p; size_t bytes; } ns_span;
+int ns_zero_spans(const ns_span* spans, int n, void* stream);
+int ns_add_i32(int32_t* counter_dev, int32_t v, void* stream);
 
 /* batched fp32 -> fp16 operand refresh after an optimizer step:
  * dst[r][c] = scale*src[r][c]  or (transpose) dst[c][r] = scale*src[r][c] */

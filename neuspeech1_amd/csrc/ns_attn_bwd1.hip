@@ -585,8 +585,8 @@ int ns_attn_bwd1_launch(const ns_attn_desc* d, void* workspace, size_t workspace
 #else
   (void)items;
 #endif
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); });
+  static ns_dev_once attr_once;
+  if (!ns_dyn_lds_once(attr_once, {(const void*)attn_bwd1_kernel}, LDS_TOTAL, "ns_attn_bwd (one pass)")) return NS_ERR_HIP;
   hipLaunchKernelGGL(attn_bwd1_kernel, dim3(d->B * d->H), dim3(NT), LDS_TOTAL, st, *d, (float*)workspace);
   NS_CHECK_LAUNCH("ns_attn_bwd (one pass)");
   return NS_OK;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <initializer_list>
 #include "../../include/neuspeech_hip.h"
 
 typedef _Float16 half_t;
@@ -29,6 +31,27 @@ void ns_set_error(const char* fmt, ...);
       return NS_ERR_BAD_ARG;                        \
     }                                               \
   } while (0)
+
+// Kernel attributes (the opt-in to more than 64 KiB of dynamic LDS) belong to the function ON ONE DEVICE: a once-flag per process
+// leaves a second device's copy of the kernel without it, and its first launch there fails with an opaque error.  One bit per
+// device ordinal; hipFuncSetAttribute is idempotent, so two threads racing through a device's first launch is harmless.  Returns
+// false with the error text set when the runtime refuses (callers return NS_ERR_HIP).
+struct ns_dev_once { std::atomic<uint64_t> done{0}; };
+inline bool ns_dyn_lds_once(ns_dev_once& o, std::initializer_list<const void*> fns, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (o.done.load(std::memory_order_acquire) & bit) return true;
+  for (const void* f : fns) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      ns_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+      return false;
+    }
+  }
+  o.done.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 
 #define NS_CHECK_LAUNCH(name)                                              \
   do {                                                                     \

@@ -342,12 +342,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ns_gemm_kernel(const ns_gemm_desc
 }
 
 template <bool TN, int BN, bool DROP>
-void launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
-  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_kernel<TN, BN, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-  });
+int launch(const ns_gemm_desc* d, dim3 grid, size_t lds, hipStream_t st) {
+  static ns_dev_once attr_once;      // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_kernel<TN, BN, DROP>}, 4 * TILE_BYTES, "ns_gemm")) return NS_ERR_HIP;
   hipLaunchKernelGGL((ns_gemm_kernel<TN, BN, DROP>), grid, dim3(NTHREADS), lds, st, *d);
+  return 0;
 }
 
 }  // namespace
@@ -477,22 +476,23 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NS_CHECK_ARG(!d->side_B || !(skinny || ns_gemm_skinny_ok(d) || ns_gemm_smallm_ok(d) || (d->flags & NS_GEMM_DROP_A)),
                "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
+  int rc = 0;      // a launcher fails only when the runtime refuses a kernel attribute (error text already set)
   if (tn && g_use_ring != 0 && g_use_ring != 8 && ns_gemm_tn256_ok(d)) {
-    ns_gemm_tn256_launch(d, st);   // conv-stem weight gradients: 256 x 256 LDS-DMA tiles (mode 8 = off, for A/B runs)
+    rc = ns_gemm_tn256_launch(d, st);   // conv-stem weight gradients: 256 x 256 LDS-DMA tiles (mode 8 = off, for A/B runs)
   } else if (tn && (g_use_ring || (d->flags & NS_GEMM_COLSUM_A)) && d->M % 8 == 0 && d->N % 8 == 0 && d->am.ld % 8 == 0 && d->bm.ld % 8 == 0 &&
       d->am.seg_stride % 8 == 0 && d->bm.seg_stride % 8 == 0 && d->M >= 8 && d->N >= 8) {
-    ns_gemm_tn_launch(d, st);   // row-major staging + ds_read_b64_tr_b16 fragments
+    rc = ns_gemm_tn_launch(d, st);   // row-major staging + ds_read_b64_tr_b16 fragments
   } else if (tn) {
     dim3 grid(tiles, 1, d->splits);
-    if (drop) launch<true, 128, true>(d, grid, lds, st); else launch<true, 128, false>(d, grid, lds, st);
+    rc = drop ? launch<true, 128, true>(d, grid, lds, st) : launch<true, 128, false>(d, grid, lds, st);
   } else if (!tn && d->splits > 1) {
-    ns_gemm_ring_launch(d, st);
+    rc = ns_gemm_ring_launch(d, st);
   } else if (g_use_ring != 0 && g_use_ring != 7 && ns_gemm_skinny_ok(d)) {
-    ns_gemm_skinny_launch(d, st);   // LoRA down-projections at training size: one stream over x (mode 7 = off, for A/B runs)
+    rc = ns_gemm_skinny_launch(d, st);   // LoRA down-projections at training size: one stream over x (mode 7 = off, for A/B runs)
   } else if (g_use_ring != 6 && g_use_ring != 0 && ns_gemm_smallm_ok(d)) {
-    ns_gemm_smallm_launch(d, st);   // decode shapes: 32x32 tiles, K split over the four waves (mode 6 = off, for A/B runs)
+    rc = ns_gemm_smallm_launch(d, st);   // decode shapes: 32x32 tiles, K split over the four waves (mode 6 = off, for A/B runs)
   } else if (skinny) {
-    if (drop) launch<false, 32, true>(d, dim3(tiles), lds, st); else launch<false, 32, false>(d, dim3(tiles), lds, st);
+    rc = drop ? launch<false, 32, true>(d, dim3(tiles), lds, st) : launch<false, 32, false>(d, dim3(tiles), lds, st);
   } else if (g_use_ring && !(d->flags & NS_GEMM_DROP_A)) {
     // 0 = register-staged kernel, 1 = auto, 2 = force the 128^2 ring, 3 = force the one-barrier 256^2 ring,
     // 4 = force the phase-interleaved 256^2 kernel where it applies, 5 = auto without the phase-interleaved kernel,
@@ -507,19 +507,20 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     // the persistent form (one workgroup per CU walks its tiles, epilogue / next-prologue overlap) where its 32-bit epilogue addressing
     // applies and a CU gets about three or more tiles (NS_P8S_MIN_TILES; below that the one-tile form with its dynamic tile order is as fast or faster); mode 4 forces the one-tile-per-workgroup form (A/B runs)
     const bool pers = big && p8_ok && ((g_use_ring == 1 && tiles256 >= NS_P8S_MIN_TILES && !(d->flags & (1 << 27))) || g_use_ring == 9) && ns_gemm_p8s_ok(d);
-    if (pers) ns_gemm_p8s_launch(d, st);
-    else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) ns_gemm_p8_launch(d, st);
+    if (pers) rc = ns_gemm_p8s_launch(d, st);
+    else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) rc = ns_gemm_p8_launch(d, st);
     else {
       // only ns_gemm_p8_kernel forms the side product: any other kernel would leave side_out unwritten and the caller's
       // ns_gemm_side_reduce would sum garbage -- refuse instead (e.g. a shape past ns_gemm_p8_fits' 2 GiB limit)
       NS_CHECK_ARG(!d->side_B, "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
-      if (big) ns_gemm_ring256_launch(d, st);
-      else ns_gemm_ring_launch(d, st);
+      if (big) rc = ns_gemm_ring256_launch(d, st);
+      else rc = ns_gemm_ring_launch(d, st);
     }
   } else {
     NS_CHECK_ARG(!d->side_B, "ns_gemm: side product requested but this shape does not dispatch to the phase-interleaved kernel");
-    if (drop) launch<false, 128, true>(d, dim3(tiles), lds, st); else launch<false, 128, false>(d, dim3(tiles), lds, st);
+    rc = drop ? launch<false, 128, true>(d, dim3(tiles), lds, st) : launch<false, 128, false>(d, dim3(tiles), lds, st);
   }
+  if (rc != 0) return rc;
   NS_CHECK_LAUNCH("ns_gemm");
   return NS_OK;
 }

@@ -577,11 +577,9 @@ bool ns_gemm_p8_fits(const ns_gemm_desc* d) {
 
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)ns_gemm_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  });
+  static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_p8_kernel<false>, (const void*)ns_gemm_p8_kernel<true>}, LDS_BYTES, "ns_gemm (p8)"))
+    return NS_ERR_HIP;
   if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_p8_kernel<true>, dim3(tiles), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL(ns_gemm_p8_kernel<false>, dim3(tiles), dim3(NTH), LDS_BYTES, st, *d);
   return 0;

@@ -695,9 +695,7 @@ void launch_kind(const ns_gemm_desc* d, int grid, hipStream_t st) {
 }
 
 template <bool DROP, int KIND, bool K2LDS>
-void set_lds_attr() {
-  hipFuncSetAttribute((const void*)ns_gemm_p8s_kernel<DROP, KIND, K2LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-}
+const void* kfn() { return (const void*)ns_gemm_p8s_kernel<DROP, KIND, K2LDS>; }
 
 }  // namespace
 
@@ -719,13 +717,17 @@ bool ns_gemm_p8s_ok(const ns_gemm_desc* d) {
 
 int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  static std::once_flag attr_once;   // lazily created immutable kernel attributes: std::call_once (include/neuspeech_hip.h, threading)
+  static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once,
+                       {kfn<false, NS_EPI_PLAIN, false>(), kfn<false, NS_EPI_RES, false>(), kfn<false, NS_EPI_DGELU, false>(),
+                        kfn<true, NS_EPI_PLAIN, false>(), kfn<true, NS_EPI_RES, false>(), kfn<true, NS_EPI_DGELU, false>(),
+                        kfn<false, NS_EPI_PLAIN, true>(), kfn<false, NS_EPI_RES, true>(), kfn<false, NS_EPI_DGELU, true>(),
+                        kfn<true, NS_EPI_PLAIN, true>(), kfn<true, NS_EPI_RES, true>(), kfn<true, NS_EPI_DGELU, true>()},
+                       LDS_BYTES, "ns_gemm (p8s)"))
+    return NS_ERR_HIP;
+  static std::once_flag cu_once;     // every device of a node is the same part: the CU count is read once
   static int cus_per_xcd = 32;
-  std::call_once(attr_once, [&] {
-    set_lds_attr<false, NS_EPI_PLAIN, false>(); set_lds_attr<false, NS_EPI_RES, false>(); set_lds_attr<false, NS_EPI_DGELU, false>();
-    set_lds_attr<true, NS_EPI_PLAIN, false>(); set_lds_attr<true, NS_EPI_RES, false>(); set_lds_attr<true, NS_EPI_DGELU, false>();
-    set_lds_attr<false, NS_EPI_PLAIN, true>(); set_lds_attr<false, NS_EPI_RES, true>(); set_lds_attr<false, NS_EPI_DGELU, true>();
-    set_lds_attr<true, NS_EPI_PLAIN, true>(); set_lds_attr<true, NS_EPI_RES, true>(); set_lds_attr<true, NS_EPI_DGELU, true>();
+  std::call_once(cu_once, [&] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
       cus_per_xcd = cus / 8;

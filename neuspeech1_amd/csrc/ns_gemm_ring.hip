@@ -232,13 +232,11 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   // columns = 88 tiles): such launches are bound by what ONE CU can fetch, and 176 workgroups move 3/4 of the bytes per CU
   const bool small = splits == 1 && tiles128 <= 384 && d->M > 64;
   const size_t lds = NST * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
-  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    hipFuncSetAttribute((const void*)ns_gemm_ring_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  });
+  static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_ring_kernel<false, 128>, (const void*)ns_gemm_ring_kernel<true, 128>,
+                                   (const void*)ns_gemm_ring_kernel<false, 64>, (const void*)ns_gemm_ring_kernel<true, 64>},
+                       64 * 1024, "ns_gemm (ring)"))
+    return NS_ERR_HIP;
   if (small) {
     const int tiles = ((d->M + 63) / 64) * tn;
     if (d->drop_p > 0.f) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 64>), dim3(tiles, 1), dim3(NTH), lds, st, *d);

@@ -188,11 +188,10 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring256_kernel(const ns_gemm_d
 int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   const size_t lds = 2 * STAGE_BYTES;
-  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_ring256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)ns_gemm_ring256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
+  static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_ring256_kernel<false>, (const void*)ns_gemm_ring256_kernel<true>}, (int)lds,
+                       "ns_gemm (ring256)"))
+    return NS_ERR_HIP;
   if (d->drop_p > 0.f) hipLaunchKernelGGL(ns_gemm_ring256_kernel<true>, dim3(tiles), dim3(NTH), lds, st, *d);
   else hipLaunchKernelGGL(ns_gemm_ring256_kernel<false>, dim3(tiles), dim3(NTH), lds, st, *d);
   return 0;

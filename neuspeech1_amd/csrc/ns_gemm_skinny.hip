@@ -128,24 +128,23 @@ __global__ __launch_bounds__(SK_NT, 1) void ns_gemm_skinny_kernel(const ns_gemm_
 }
 
 template <int NTILES, bool DROP, int DEPTH>
-void sk_launch3(const ns_gemm_desc* d, hipStream_t st, int grid, size_t lds) {
-  static std::once_flag once;
-  std::call_once(once, [] {
-    hipFuncSetAttribute((const void*)ns_gemm_skinny_kernel<NTILES, DROP, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+int sk_launch3(const ns_gemm_desc* d, hipStream_t st, int grid, size_t lds) {
+  static ns_dev_once once;           // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(once, {(const void*)ns_gemm_skinny_kernel<NTILES, DROP, DEPTH>}, 160 * 1024, "ns_gemm (skinny)")) return NS_ERR_HIP;
   hipLaunchKernelGGL((ns_gemm_skinny_kernel<NTILES, DROP, DEPTH>), dim3(grid), dim3(SK_NT), lds, st, *d);
+  return 0;
 }
 
 template <int NTILES>
-void sk_launch(const ns_gemm_desc* d, hipStream_t st) {
+int sk_launch(const ns_gemm_desc* d, hipStream_t st) {
   const size_t lds = (size_t)d->K * 16 * NTILES * 2;
   const int nblk = (d->M + 15) / 16;
   int grid = (nblk + SK_WAVES - 1) / SK_WAVES;
   if (grid > 256) grid = 256;                               // one workgroup per CU, row blocks strided over its waves
   const bool drop = d->drop_p > 0.f && (d->flags & NS_GEMM_DROP_A);
   const bool deep = (d->K >> 6) % 8 == 0;
-  if (drop) { if (deep) sk_launch3<NTILES, true, 8>(d, st, grid, lds); else sk_launch3<NTILES, true, 4>(d, st, grid, lds); }
-  else { if (deep) sk_launch3<NTILES, false, 8>(d, st, grid, lds); else sk_launch3<NTILES, false, 4>(d, st, grid, lds); }
+  if (drop) return deep ? sk_launch3<NTILES, true, 8>(d, st, grid, lds) : sk_launch3<NTILES, true, 4>(d, st, grid, lds);
+  return deep ? sk_launch3<NTILES, false, 8>(d, st, grid, lds) : sk_launch3<NTILES, false, 4>(d, st, grid, lds);
 }
 
 }  // namespace
@@ -162,6 +161,5 @@ bool ns_gemm_skinny_ok(const ns_gemm_desc* d) {
 }
 
 int ns_gemm_skinny_launch(const ns_gemm_desc* d, hipStream_t st) {
-  if (d->N == 32) sk_launch<2>(d, st); else sk_launch<6>(d, st);
-  return 0;
+  return d->N == 32 ? sk_launch<2>(d, st) : sk_launch<6>(d, st);
 }

@@ -192,14 +192,13 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
 }
 
 template <int BI, int BJ, bool DROP>
-void launch_tn(const ns_gemm_desc* d, hipStream_t st) {
+int launch_tn(const ns_gemm_desc* d, hipStream_t st) {
   const int tiles = ((d->M + BI - 1) / BI) * ((d->N + BJ - 1) / BJ);
   const size_t lds = 2 * (size_t)BKM * (RowStride<BI>::bytes + RowStride<BJ>::bytes);
-  static std::once_flag attr_once;   // lazily created immutable kernel attribute: std::call_once (include/neuspeech_hip.h, threading)
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute((const void*)ns_gemm_tn_kernel<BI, BJ, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
+  static ns_dev_once attr_once;      // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_tn_kernel<BI, BJ, DROP>}, (int)lds, "ns_gemm (tn)")) return NS_ERR_HIP;
   hipLaunchKernelGGL((ns_gemm_tn_kernel<BI, BJ, DROP>), dim3(tiles, 1, d->splits), dim3(NTH), lds, st, *d);
+  return 0;
 }
 
 }  // namespace
@@ -208,8 +207,7 @@ void launch_tn(const ns_gemm_desc* d, hipStream_t st) {
 int ns_gemm_tn_launch(const ns_gemm_desc* d, hipStream_t st) {
   const bool drop = d->drop_p > 0.f;
   // (M in (32, 128] -- the stacked q|k|v bottleneck, 3r = 96 rows -- takes the 128-row tile: B is read, and masked, once)
-  if (d->M <= 32) { if (drop) launch_tn<32, 128, true>(d, st); else launch_tn<32, 128, false>(d, st); }
-  else if (d->N <= 96) { if (drop) launch_tn<128, 32, true>(d, st); else launch_tn<128, 32, false>(d, st); }
-  else { if (drop) launch_tn<128, 128, true>(d, st); else launch_tn<128, 128, false>(d, st); }
-  return 0;
+  if (d->M <= 32) return drop ? launch_tn<32, 128, true>(d, st) : launch_tn<32, 128, false>(d, st);
+  if (d->N <= 96) return drop ? launch_tn<128, 32, true>(d, st) : launch_tn<128, 32, false>(d, st);
+  return drop ? launch_tn<128, 128, true>(d, st) : launch_tn<128, 128, false>(d, st);
 }

@@ -199,10 +199,8 @@ int ns_gemm_tn256_launch(const ns_gemm_desc* d, hipStream_t st) {
   if (splits < 1) splits = 1;
   while (splits > 1 && d->K / splits < 512) --splits;
   const int total = tiles * splits;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    hipFuncSetAttribute((const void*)ns_gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-  });
+  static ns_dev_once once;           // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(once, {(const void*)ns_gemm_tn256_kernel}, T_LDS_BYTES, "ns_gemm (tn256)")) return NS_ERR_HIP;
   const int grid = ((total + 7) / 8) * 8;
   hipLaunchKernelGGL(ns_gemm_tn256_kernel, dim3(grid), dim3(T_NTH), T_LDS_BYTES, st, *d, splits, tiles_j, total);
   return 0;

@@ -267,12 +267,11 @@ __global__ __launch_bounds__(256) void lora_bwd_reduce_kernel(const ns_lora_bwd_
 }
 
 template <int G, int NSUB>
-void launch(const ns_lora_bwd_desc* d, int grid, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [&] {
-    hipFuncSetAttribute((const void*)lora_bwd_dudb_kernel<G, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  });
+int launch(const ns_lora_bwd_desc* d, int grid, hipStream_t st) {
+  static ns_dev_once once;           // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(once, {(const void*)lora_bwd_dudb_kernel<G, NSUB>}, LDS_BYTES, "ns_lora_bwd_dudb")) return NS_ERR_HIP;
   hipLaunchKernelGGL((lora_bwd_dudb_kernel<G, NSUB>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  return 0;
 }
 
 }  // namespace
@@ -307,9 +306,11 @@ extern "C" int ns_lora_bwd_dudb(const ns_lora_bwd_desc* d, void* stream) {
                "ns_lora_bwd_dudb: workspace of %zu bytes is smaller than ns_lora_bwd_workspace_bytes()", (size_t)d->workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   const int nsub = d->N / SC;
-#define NS_LB(G_, S_) if (d->G == G_ && nsub == S_) { launch<G_, S_>(d, grid, st); }
+  int rc = 0;
+#define NS_LB(G_, S_) if (d->G == G_ && nsub == S_) { rc = launch<G_, S_>(d, grid, st); }
   NS_LB(1, 1) else NS_LB(1, 2) else NS_LB(1, 5) else NS_LB(1, 8) else NS_LB(3, 1) else NS_LB(3, 2)
 #undef NS_LB
+  if (rc != 0) return rc;
   if (d->workspace) {
     hipLaunchKernelGGL(lora_bwd_reduce_kernel, dim3(d->G * d->N / 2), dim3(256), 0, st, *d, grid);
   }

@@ -10,7 +10,7 @@ void ns_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-extern "C" int ns_version(void) { return 2; }   // 2: ns_gemm_desc.seed_dev
+extern "C" int ns_version(void) { return 3; }   // 2: ns_gemm_desc.seed_dev; 3: ns_zero_spans / ns_add_i32
 extern "C" const char* ns_last_error(void) { return g_err; }
 
 namespace {
@@ -392,6 +392,21 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// up to NS_ZERO_MAX_SPANS buffers cleared by ONE launch (blockIdx.y = span): 16-B lane stores, a dword tail
+struct zero_spans_arg { ns_span s[NS_ZERO_MAX_SPANS]; };
+__global__ __launch_bounds__(256) void zero_spans_kernel(const zero_spans_arg a) {
+  const ns_span sp = a.s[blockIdx.y];
+  const size_t n16 = sp.bytes >> 4;
+  uint4* const p16 = (uint4*)sp.p;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
+  if (blockIdx.x == 0) {
+    uint32_t* const p4 = (uint32_t*)sp.p;
+    for (size_t i = (n16 << 2) + threadIdx.x; i < (sp.bytes >> 2); i += blockDim.x) p4[i] = 0u;
+  }
+}
+__global__ void add_i32_kernel(int32_t* p, int32_t v) { *p += v; }
+
 }  // namespace
 
 extern "C" int ns_signal_pack(const float* x, void* out16, int B, int ch, int T, int Cp, void* stream) {
@@ -493,5 +508,32 @@ extern "C" int ns_orth_reg(const ns_orth_job* jobs_dev, int njobs, float weight_
   hipLaunchKernelGGL(orth_grad_kernel, dim3(njobs, ORTH_SPLIT), dim3(256), 0, st, jobs_dev, (const float*)workspace, weight_over_num,
                      loss_scale_dev, reg_out_dev);
   NS_CHECK_LAUNCH("ns_orth_reg");
+  return NS_OK;
+}
+
+extern "C" int ns_zero_spans(const ns_span* spans, int n, void* stream) {
+  NS_CHECK_ARG(spans && n > 0 && n <= NS_ZERO_MAX_SPANS, "ns_zero_spans: 1..%d spans (got %d)", NS_ZERO_MAX_SPANS, n);
+  zero_spans_arg a;
+  size_t most = 0;
+  for (int i = 0; i < NS_ZERO_MAX_SPANS; ++i) {
+    a.s[i] = i < n ? spans[i] : ns_span{nullptr, 0};
+    if (i < n) {
+      NS_CHECK_ARG(spans[i].p && ((uintptr_t)spans[i].p & 15) == 0 && (spans[i].bytes & 3) == 0,
+                   "ns_zero_spans: span %d must be 16-byte aligned with a multiple of 4 bytes", i);
+      most = spans[i].bytes > most ? spans[i].bytes : most;
+    }
+  }
+  if (most == 0) return NS_OK;
+  const size_t blocks = (most / 16 + 1023) / 1024;      // four 16-B stores per thread and pass
+  hipLaunchKernelGGL(zero_spans_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), n), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  NS_CHECK_LAUNCH("ns_zero_spans");
+  return NS_OK;
+}
+
+extern "C" int ns_add_i32(int32_t* counter_dev, int32_t v, void* stream) {
+  NS_CHECK_ARG(counter_dev, "ns_add_i32: null pointer");
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, v);
+  NS_CHECK_LAUNCH("ns_add_i32");
   return NS_OK;
 }

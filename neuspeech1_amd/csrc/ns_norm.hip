@@ -297,10 +297,8 @@ extern "C" int ns_layernorm_fwd_lora(const float* x, const float* gamma, const f
   const float a = alpha == 0.f ? 1.f : alpha;
 #define LNL(VEC_, NT_, DR_)                                                                                                              \
   do {                                                                                                                                   \
-    static std::once_flag once;                                                                                                          \
-    std::call_once(once, [] {                                                                                                            \
-      hipFuncSetAttribute((const void*)ln_fwd_lora_kernel<VEC_, NT_, DR_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
-    });                                                                                                                                  \
+    static ns_dev_once once;                                                                                                             \
+    if (!ns_dyn_lds_once(once, {(const void*)ln_fwd_lora_kernel<VEC_, NT_, DR_>}, 160 * 1024, "ns_layernorm_fwd_lora")) return NS_ERR_HIP; \
     hipLaunchKernelGGL((ln_fwd_lora_kernel<VEC_, NT_, DR_>), dim3(grid), dim3(512), lds, st, x, gamma, beta, (half_t*)y16, mean, rstd, rows, \
                        eps, (const half_t*)A16, lda, (half_t*)u16, ldu, a, drop_p, drop_seed, seed_dev);                                  \
   } while (0)

@@ -198,7 +198,7 @@ class MegWhisperEngine:
         self._bufs = {}
         # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
         self.use_graph = os.environ.get("NS_TRAIN_GRAPH", "1") != "0"
-        self._graphs, self._graph_warm, self.graph_cache, self._graph_failures = {}, set(), 48, 0
+        self._graphs, self._graph_warm, self.graph_cache = {}, set(), 48
         self._graph_captures = self._graph_failed_total = self._graph_replays = self._graph_evictions = 0
         self._graph_graveyard = []
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
@@ -473,8 +473,8 @@ class MegWhisperEngine:
         T, S, Cp = dims.T, dims.src_pos, dims.ch_pad
         M = B * S
         dev = self.dev
-        h16 = lambda *s: torch.zeros(*s, device=dev, dtype=F16)  # noqa: E731  (zeros: halo rows must be 0)
-        f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
+        h16 = lambda *s: ops.zeros(*s, device=dev, dtype=F16)  # noqa: E731  (zeros: halo rows must be 0; cleared by ns_zero_spans)
+        f32 = lambda *s: ops.zeros(*s, device=dev, dtype=F32)  # noqa: E731
         b = {"B": B}
         b["xin"] = h16(B, T + 2, Cp)
         if self.frontend == "base":
@@ -538,8 +538,8 @@ class MegWhisperEngine:
         dims, d, f, r, H = self.dims, self.dims.d, self.dims.ffn, self.r, self.dims.heads
         ML = B * L
         dev = self.dev
-        h16 = lambda *s: torch.zeros(*s, device=dev, dtype=F16)  # noqa: E731
-        f32 = lambda *s: torch.zeros(*s, device=dev, dtype=F32)  # noqa: E731
+        h16 = lambda *s: ops.zeros(*s, device=dev, dtype=F16)  # noqa: E731
+        f32 = lambda *s: ops.zeros(*s, device=dev, dtype=F32)  # noqa: E731
         nd = dims.dec_layers
         ndl = nd if train else 1
         b = {}
@@ -560,7 +560,7 @@ class MegWhisperEngine:
         b["st_d"] = (f32(ML), f32(ML))
         b["logits"] = h16(ML, dims.vocab_pad)
         b["row_loss"] = f32(ML)
-        b["dec_ids"] = torch.zeros(B, L, device=dev, dtype=torch.int64)
+        b["dec_ids"] = ops.zeros(B, L, device=dev, dtype=torch.int64)
         if train:
             if self.dec_lora:
                 b["ddu"] = h16(ML, 3 * r)
@@ -851,7 +851,7 @@ class MegWhisperEngine:
             loss = self.loss_dev
             if self.adalora and compute_grad:
                 # AdaLoRA's orthogonality regulariser (value into reg_dev, gradient into G, which the caller zeroed)
-                self.reg_dev.zero_()
+                ops.zero_(self.reg_dev)
                 ops.orth_reg(self._orth_table, self._n_orth, self.lora.orth_reg_weight / self._n_orth,
                              self.loss_scale_dev, self.reg_dev)
                 torch.add(self.loss_dev, self.reg_dev, out=self.total_loss_dev)     # static buffer: graph replays write it too
@@ -874,7 +874,7 @@ class MegWhisperEngine:
         tiles = ((ML + 127) // 128) * ((d + 127) // 128)
         splits = max(1, min(64, Vp // 2048, -(-1024 // tiles)))
         if splits > 1:
-            b["ddx32"].zero_()
+            ops.zero_(b["ddx32"])
             self._gemm(A=b["logits"], am=rowmap(Vp), K=Vp, B=self.E16T, ldb=Vp, M=ML, N=d, C32=b["ddx32"], ldc32=d, splits=splits)
             ops.layernorm_bwd(b["ddx32"], True, hd[3 * dims.dec_layers], *b["st_d"], self.dec_ln[0], None, b["ddh32"],
                               b["ddh16"], ML, d)
@@ -1002,7 +1002,7 @@ class MegWhisperEngine:
             self._wgrad(dy16, ldy, u16, ldu, Mred, N, r, key + ".lora_B", alpha=s)
             return
         tmp = self._gbf[:N * r]
-        tmp.zero_()
+        ops.zero_(tmp)
         self._gemm(A=dy16, am=rowmap(ldy), K=Mred, B=u16, bm=rowmap(ldu), M=N, N=r, C32=tmp, ldc32=r,
                  flags=NS_GEMM_TN | NS_GEMM_ATOMIC32, splits=max(1, min(Mred // 256, -(-384 // ((N + 127) // 128)))))
         en = ename or key + ".lora_E"
@@ -1026,7 +1026,7 @@ class MegWhisperEngine:
                 al = [1.0] * G
             elif self.adalora:
                 tmp = self._gbf3[:G * N * r].view(G, N * r)
-                tmp.zero_()
+                ops.zero_(tmp)
                 dB = [tmp[g] for g in range(G)]
                 al = [1.0] * G
             else:
@@ -1095,7 +1095,7 @@ class MegWhisperEngine:
 
     # ------------------------------------------------------------------ optimizer
     def zero_grad(self):
-        self.G.zero_()
+        ops.zero_(self.G)       # a kernel (ns_zero_spans), not a memset node: the step is replayed from hipGraphs
 
     def optimizer_step(self):
         tc = self.tc
@@ -1106,7 +1106,7 @@ class MegWhisperEngine:
                        self.found_inf_dev, self.loss_scale_dev if tc.fp16_scaler else None,
                        self.growth_dev if tc.fp16_scaler else None)
         self.refresh_operands()
-        self.seed_ctr.add_(1)       # next step, next dropout masks (device-side: see _init_opt_state)
+        ops.add_i32(self.seed_ctr, 1)   # next step, next dropout masks (device-side: see _init_opt_state)
 
     def train_step(self, x32, labels, on_ready=None, reduce_fn=None):
         """forward + backward (+ optional gradient reduction) + optimizer; returns the device loss scalar.
@@ -1147,22 +1147,22 @@ class MegWhisperEngine:
             try:
                 g = self._capture_step(x32, labels, cut)
                 self._graph_captures += 1
-                self._graph_failures = max(0, self._graph_failures - 1)     # strikes decay: three failures IN A ROW disable graphs
             except RuntimeError as e:
                 # another host thread outside this package's capture lock (e.g. torch's pin-memory thread) can invalidate a
-                # capture on HIP: nothing has executed, so run this step eagerly and try again later, a bounded number of times.
+                # capture on HIP: nothing has executed, so run this step eagerly.
                 # torch.cuda.graph.__exit__ ends the capture BEFORE it leaves its side stream: when capture_end raises, the
                 # capture stream would stay current (the eager step, the prefetcher's wait_stream / record_stream and the
                 # allocator's stream ownership would all move to it) -- put the caller's stream back
                 torch.cuda.synchronize()
                 torch.cuda.set_stream(prev_stream)
-                self._graph_failures += 2
                 self._graph_failed_total += 1
-                if self._graph_failures >= 6:
-                    self.use_graph = False
+                # best effort only: the graveyard keeps the dead graph objects and their pool alive, but a truly
+                # invalidated capture has been seen to abort later inside the allocator; a second attempt doubles that exposure
+                # and, under DP, a rank that dies mid-run hangs the others in RCCL.  One real failure ends graph use for the run.
+                self.use_graph = False
                 import warnings
-                warnings.warn(f"train_step: hipGraph capture failed ({str(e).splitlines()[0][:120]}); eager step "
-                              f"({'graphs disabled' if not self.use_graph else 'will retry'})")
+                warnings.warn(f"train_step: hipGraph capture failed ({str(e).splitlines()[0][:120]}); eager steps from here on "
+                              "(graphs disabled for this engine)")
                 return self._train_step_eager(x32, labels, on_ready, reduce_fn)
             if len(self._graphs) >= self.graph_cache:        # least recently used first (hits move a key to the end)
                 self._graphs.pop(next(iter(self._graphs)))
@@ -1173,6 +1173,11 @@ class MegWhisperEngine:
         if packed:
             x32.acquire()            # the copy stream's event: waited for eagerly, never inside a capture
         else:
+            # the same contract encode() asserts on the eager path: the pack below reads the raw pointer
+            if not (x32.dtype == F32 and x32.is_contiguous() and x32.device == self.dev
+                    and tuple(x32.shape) == (x32.shape[0], self.dims.ch, self.dims.T)):
+                raise ValueError(f"train_step: the batch must be a contiguous float32 (B, {self.dims.ch}, {self.dims.T}) tensor on "
+                                 f"{self.dev} (got {x32.dtype}, {tuple(x32.shape)}, {x32.device}, contiguous={x32.is_contiguous()})")
             ops.signal_pack(x32, g["b"]["xin"], x32.shape[0], self.dims.ch, self.dims.T, self.dims.ch_pad)
         g["labels"].copy_(labels, non_blocking=True)
         self.training_mode = True

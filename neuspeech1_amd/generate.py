@@ -79,11 +79,13 @@ class Generator:
                  repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0, suppress_tokens=(),
                  begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
                  pad_id: int | None = None, check_every: int = 4, sequence_bias=None, forced_decoder_ids=None,
-                 begin_index: int | None = None) -> torch.Tensor:
+                 begin_index: int | None = None, trace: list | None = None) -> torch.Tensor:
         """forced_decoder_ids: [[position, token or None], ...] (generation_config.forced_decoder_ids as the reference's
         wrapper passes them on, utils/load_model.py:1210-1256): HF ForceTokensLogitsProcessor semantics, position =
         absolute index in the decoder sequence.  begin_index: the position the begin-suppress list applies at (default:
-        the prompt length; HF of the reference's era adds forced_decoder_ids[-1][0])."""
+        the prompt length; HF of the reference's era adds forced_decoder_ids[-1][0]).  trace (tests only, greedy only): a list
+        that receives, per selection step, (values, columns) of each row's two best PROCESSED scores -- this path's own
+        decision margin, what tests/test_live_fp16_gpu.py holds a flipped token against; the loop then stays eager."""
         eng = self.eng
         if getattr(eng, "dec_lora", False):
             raise RuntimeError("decode from merged weights (merge_and_unload / merge_lora.py): the generation loop does not "
@@ -212,7 +214,7 @@ class Generator:
         next_tok = torch.empty(Bp, device=dev, dtype=torch.int64)
         cur = P
 
-        graph_ok = self.use_graph and dev.type == "cuda"
+        graph_ok = self.use_graph and dev.type == "cuda" and trace is None
 
         def run_loop(select, ping_pong):
             """select(cur, ctr) picks token `cur` from `logits` (and reverses the lists in `ping_pong`); the step then
@@ -265,8 +267,17 @@ class Generator:
             cand_v = torch.empty(Bp, device=dev, dtype=F32)
             cand_i = torch.empty(Bp, device=dev, dtype=torch.int32)
 
+            if trace is not None and not fused_select:
+                raise ValueError("trace needs the fused selection kernel (vocabulary within SELECT_MAX_LDV, no NS_NO_FUSED_SELECT)")
+            tr_v = torch.empty(Bp, 2, device=dev, dtype=F32) if trace is not None else None
+            tr_i = torch.empty(Bp, 2, device=dev, dtype=torch.int32) if trace is not None else None
+
             def select(c, ctr):
                 flags.zero_()
+                if trace is not None:       # this step's two best processed scores per row, before the ids move on
+                    ops.logits_select(ids=seqs[0], cur_len=c, log_softmax=False, cur_len_dev=ctr, k=2, group_rows=1,
+                                      cand_vals=tr_v, cand_idx=tr_i, **proc)
+                    trace.append((tr_v.clone(), tr_i.clone()))
                 if fused_select:
                     ops.logits_select(ids=seqs[0], cur_len=c, log_softmax=False, cur_len_dev=ctr, k=1, group_rows=1,
                                       cand_vals=cand_v, cand_idx=cand_i, **proc)

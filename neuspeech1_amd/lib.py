@@ -24,7 +24,7 @@ class NeuSpeechHipError(RuntimeError):
 import threading  # noqa: E402
 GPU_CAPTURE_LOCK = threading.RLock()
 
-ABI_VERSION = 2      # ns_version() of the library this binding was written against (ns_gemm_desc.seed_dev)
+ABI_VERSION = 3      # ns_version() of the library this binding was written against (3: ns_zero_spans / ns_add_i32)
 
 
 class RowMap(C.Structure):
@@ -55,6 +55,10 @@ class GemmDesc(C.Structure):
         ("side_drop_p", C.c_float), ("side_drop_seed", C.c_uint32),
         ("seed_dev", C.c_void_p),
     ]
+
+
+class Span(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("bytes", C.c_size_t)]
 
 
 class CastJob(C.Structure):
@@ -187,6 +191,8 @@ SIGNATURES = {
     "ns_dgelu_mul": (C.c_int, [_vp, _vp, _vp, C.POINTER(RowMap), _i, _i, _i, _vp]),
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
+    "ns_zero_spans": (C.c_int, [C.POINTER(Span), _i, _vp]),
+    "ns_add_i32": (C.c_int, [_vp, C.c_int32, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_adalora_fold_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_gemm_side_supported": (C.c_int, [_i, _i, _i]),

@@ -191,6 +191,29 @@ def adamw_step(p, g, m, v, n, cfg: AdamWCfg, step_dev, norm2_dev, found_inf_dev,
             "ns_adamw_step")
 
 
+def zero_(*tensors):
+    """clear up to 8 tensors per launch with ns_zero_spans (a kernel, never a memset node: see the header)"""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for i in range(0, len(ts), 8):
+        chunk = ts[i:i + 8]
+        arr = (L.Span * len(chunk))()
+        for j, t in enumerate(chunk):
+            assert t.is_contiguous()
+            arr[j] = L.Span(t.data_ptr(), t.numel() * t.element_size())
+        L.check(L.load().ns_zero_spans(arr, len(chunk), _stream()), "ns_zero_spans")
+
+
+def zeros(*shape, device, dtype):
+    """torch.zeros without torch's fill kernel"""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    zero_(t)
+    return t
+
+
+def add_i32(counter_dev, v=1):
+    L.check(L.load().ns_add_i32(ptr(counter_dev), int(v), _stream()), "ns_add_i32")
+
+
 def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
     """jobs: list of (src_ptr, dst_ptr, rows, cols, ld_src, ld_dst, scale, transpose) -> device table."""
     arr = (CastJob * len(jobs))()

@@ -13,7 +13,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(so, name), f"{name} declared in the header but not exported"
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert so.ns_version() == 2 and so.ns_last_error() is not None
+    assert so.ns_version() == 3 and so.ns_last_error() is not None
 
 
 def test_bad_arguments_fail_loudly_without_gpu():

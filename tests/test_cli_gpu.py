@@ -446,9 +446,12 @@ def test_finetune_two_ranks_data_parallel_on_one_gpu(dev, tmp_path):
         assert abs(a["loss"] - b["loss"]) < 1e-2 * b["loss"], (ddp_logs, one_logs)
 
 
-def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
+@pytest.mark.parametrize("world,batch", [(2, 4), (8, 2)])
+def test_bench_contract_with_n_ranks_on_one_gpu(dev, tmp_path, world, batch):
     """bench.py under the driver's multi-GPU launch line (one rank per process, barrier + max-over-ranks timing, ONE JSON
-    line from rank 0, whole-job value): two ranks sharing this box's GPU over gloo, small batch."""
+    line from rank 0, whole-job value): `world` ranks sharing this box's GPU over gloo, small batch.  world = 8 is the
+    driver's largest launch: rank-count assumptions -- gradient chunk boundaries, the per-rank gathers,
+    shard seeds, the graph capture cut at the exchange points on every rank -- run at N = 8 even though no 8-GPU node exists."""
     import socket
     import subprocess
     import sys
@@ -456,16 +459,17 @@ def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"]
-    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, NS_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "2",
+           "--batch", str(batch)]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, NS_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
-    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
-    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert d["config"]["global_batch"] == world * batch and d["config"]["parallelism"] == f"dp{world}"
+    assert abs(d["value"] - world * batch * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
     assert d["roofline"]["kernel"] and d["cpu_baseline"] is None and d["vs_baseline"] is None
     # the first real multi-GPU run must yield a diagnosis, not just a number: bytes reduced per step and the part of the
     # all-reduce that backward did not hide (the optimizer stream's wait for the side stream)
@@ -475,7 +479,11 @@ def test_bench_contract_with_two_ranks_on_one_gpu(dev, tmp_path):
     # exposed < total means the chunks launched from backward's on_ready points really ran beside backward
     assert d["dp"]["allreduce_ms_per_step"] > 0.0
     assert d["dp"]["exposed_allreduce_ms_per_step"] < d["dp"]["allreduce_ms_per_step"], d["dp"]
-    assert len(d["dp"]["rank_ms_per_step"]) == 2 and d["dp"]["rank_skew_ms"] >= 0.0
+    assert len(d["dp"]["rank_ms_per_step"]) == world and d["dp"]["rank_skew_ms"] >= 0.0
+    # every rank replayed its captured step (cut at the three exchange points + the optimizer) for every timed step
+    g = d["config"]["graph"]
+    assert d["config"]["train_step_graph"] and len(g["per_rank"]) == world, g
+    assert all(p["captures"] == 1 and p["capture_failures"] == 0 and p["replays"] >= 3 for p in g["per_rank"]), g
     assert 0.0 < d["config"]["encoder_fwd_bwd_mfma_frac"] < 1.0
 
 

@@ -727,7 +727,7 @@ def test_graph_replay_with_rccl_exchange_single_rank(dev):
 def test_failed_capture_falls_back_and_restores_the_stream(dev):
     """torch.cuda.graph.__exit__ ends the capture BEFORE it leaves its side stream, so a capture_end that raises (a capture
     invalidated by a foreign host thread) leaves the capture stream current.  train_step must put the caller's stream back,
-    run the step eagerly, count and report the failure, and capture on the next attempt.  The failure is SIMULATED at
+    run the step eagerly, count and report the failure, and stop using graphs for the run.  The failure is SIMULATED at
     _capture_step's boundary (the side stream left current + the RuntimeError torch raises): really invalidating a capture
     makes this torch / HIP stack abort later, inside the allocator, when the tensors of the dead capture are released."""
     dims = TINY
@@ -747,23 +747,35 @@ def test_failed_capture_falls_back_and_restores_the_stream(dev):
         l1 = eng.train_step(xd, ld)
     assert torch.cuda.current_stream() == cur
     assert torch.isfinite(l1).all()
+    # ONE real failure ends graph use for the run (recovery from a truly invalidated capture cannot be relied on, and
+    # under DP a rank that aborts hangs the others): the step still runs, eagerly, and the stats say so
     st = eng.graph_stats()
-    assert st["capture_failures"] == 1 and st["captures"] == 0 and st["enabled"]
+    assert st["capture_failures"] == 1 and st["captures"] == 0 and not st["enabled"]
     eng._capture_step = real
     for _ in range(3):
         l2 = eng.train_step(xd, ld)
     assert torch.cuda.current_stream() == cur and torch.isfinite(l2).all()
     st = eng.graph_stats()
-    assert st["captures"] == 1 and st["replays"] == 3 and st["capture_failures"] == 1, st
-    # three failures in a row disable graphs for the run (and the stats say so)
-    eng2, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
-    eng2.train_step(xd, ld)
-    eng2._capture_step = failing_capture
-    with pytest.warns(UserWarning):
-        for _ in range(3):
-            eng2.train_step(xd, ld)
-    assert not eng2.graph_stats()["enabled"] and eng2.graph_stats()["capture_failures"] == 3
-    assert torch.cuda.current_stream() == cur
+    assert st["captures"] == 0 and st["replays"] == 0 and st["capture_failures"] == 1 and not st["enabled"], st
+
+
+def test_graph_replay_path_checks_the_batch_like_the_eager_path(dev):
+    """only the first batch of a shape goes through encode()'s asserts; a later fp16 / non-contiguous / CPU batch of the
+    same shape would be packed from garbage by the eager ns_signal_pack in front of the replay.  It must raise instead."""
+    dims = TINY
+    eng, _, _ = make_engine(dims, dev, 32, lr=1e-3, warmup_steps=0, total_steps=0)
+    x, labels = synth_batch(dims, 3, 77)
+    xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(labels).to(dev)
+    for _ in range(3):
+        eng.train_step(xd, ld)
+    assert eng.graph_stats()["replays"] >= 1
+    with pytest.raises(ValueError, match="contiguous float32"):
+        eng.train_step(xd.half(), ld)
+    with pytest.raises(ValueError, match="contiguous float32"):
+        eng.train_step(xd.transpose(1, 2).contiguous().transpose(1, 2), ld)
+    with pytest.raises(ValueError, match="contiguous float32"):
+        eng.train_step(xd.cpu(), ld)
+    assert torch.isfinite(eng.train_step(xd, ld)).all()
 
 
 def test_plain_tensor_batches_share_one_graph(dev):

@@ -85,7 +85,22 @@ def test_b128_273ch_decode_rows_equal_golden_and_small_batch_decodes(dev, name, 
         if len(neq) and nb == 1:
             assert g[name + "_margin"][b, int(neq[0]) - 4] < 0.03, (b, out[b].tolist(), ref[b].tolist())
     if nb > 1:
+        # beam rows 0 / 1: ids, under the rule of tests/test_generate_gpu.py::check_beam -- hypothesis 0 of the reference object, or
+        # (at most one row) another of ITS OWN finished hypotheses within 2e-2 of its best (tests/golden/decode_base273_hyps.npz)
         np.testing.assert_allclose(scores[:2], g[name + "_scores"], atol=2e-2)
+        hy = np.load(os.path.join(G, "decode_base273_hyps.npz"))
+        hyps, hsc = hy[name + "_hyps"], hy[name + "_hyp_scores"]
+        left = 0
+        for b in range(2):
+            def row_is(h):
+                L = min(out.shape[1], len(h))
+                return np.array_equal(out[b, :L], h[:L]) and (out[b, L:] == dims.pad_id).all() and (h[L:] == dims.pad_id).all()
+            if row_is(hyps[b, 0]):
+                continue
+            alt = [k for k in range(1, hyps.shape[1]) if row_is(hyps[b, k])]
+            assert alt and hsc[b, 0] - hsc[b, alt[0]] < 2e-2, (b, out[b].tolist(), hyps[b].tolist(), hsc[b].tolist())
+            left += 1
+        assert left <= 1
     # every row against the SAME input decoded in a batch of two
     diff, dscore = [], 0.0
     for i in range(0, 128, 2):

@@ -51,16 +51,40 @@ def check_greedy_up_to_fp16_ties(out, ref, margin, P, pad, tie=0.03):
     assert flips <= 1, flips
 
 
-def check_beam(gen, out, ref, ref_scores, pad):
-    """Beam search over a flat random-init model has near-ties: fp16 logits can flip a decision whose two branches score
-    within rounding of each other, and a row then ends on a different, equally good hypothesis.  Rule: every row
-    token-exact, except at most ONE row whose final length-normalised score still equals the reference's within 2e-2
-    (all rows' scores are compared); greedy variants get no such allowance."""
+def _row_is(row, hyp, pad):
+    L = min(len(row), len(hyp))
+    return np.array_equal(row[:L], hyp[:L]) and (row[L:] == pad).all() and (hyp[L:] == pad).all()
+
+
+def load_hyps(tag):
+    """the reference object's top-num_beams finished hypotheses of every beam golden (tools/make_goldens.py hyps)"""
+    return np.load(os.path.join(G, f"decode_{tag}_hyps.npz"))
+
+
+def check_beam(gen, out, ref, ref_scores, pad, hyps, hyp_scores):
+    """Beam search over a flat random-init model has near-ties (the reference's own second hypothesis is typically 1e-4 .. 5e-3
+    behind its first): fp16 logits can flip a decision whose two branches score within rounding of each other, and a row then
+    ends on a different hypothesis.  Rule (VERDICT r4 #3b): every row token-exact, except at most ONE row, and that row must BE
+    one of the reference object's own finished hypotheses (hyps[b, 1:], stored with the golden) whose reference score lies
+    within 2e-2 of the reference's best -- a valid alternative, not just any sequence with a similar score.  All rows' scores are
+    compared with the reference's (2e-2)."""
     got = out.cpu().numpy()
-    np.testing.assert_allclose(gen.last_scores.cpu().numpy(), ref_scores, atol=2e-2)
+    sc = gen.last_scores.cpu().numpy()
+    np.testing.assert_allclose(sc, ref_scores, atol=2e-2)
     assert got.shape == ref.shape, (got.shape, ref.shape)
-    same = [np.array_equal(got[b], ref[b]) for b in range(ref.shape[0])]
-    assert sum(same) >= ref.shape[0] - 1, (same, got.tolist(), ref.tolist())
+    B, nb = hyps.shape[:2]
+    assert B == ref.shape[0]
+    left = []
+    for b in range(B):
+        assert _row_is(ref[b], hyps[b, 0], pad)            # the hypotheses file belongs to this golden
+        if np.array_equal(got[b], ref[b]):
+            continue
+        alt = [k for k in range(1, nb) if _row_is(got[b], hyps[b, k], pad)]
+        assert alt, (b, got[b].tolist(), hyps[b].tolist())
+        k = alt[0]
+        assert hyp_scores[b, 0] - hyp_scores[b, k] < 2e-2 and abs(sc[b] - hyp_scores[b, k]) < 2e-2, (b, k, sc[b], hyp_scores[b].tolist())
+        left.append((b, k))
+    assert len(left) <= 1, (left, got.tolist(), ref.tolist())
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -246,7 +270,8 @@ def test_sequence_bias_token_ids_exact(setup, name, nb, kw):
         return
     # (row 0 of beam5_rp_sb ends on a hypothesis scoring -4.690 against the reference's -4.683); the processor itself is
     # checked against HF's classes below
-    check_beam(gen, out, g[name], g[name + "_scores"], dims.pad_id)
+    hy = load_hyps("tiny_sb")
+    check_beam(gen, out, g[name], g[name + "_scores"], dims.pad_id, hy[name + "_hyps"], hy[name + "_hyp_scores"])
 
 
 def test_sequence_bias_processor_matches_hf_processors(dev):
@@ -307,7 +332,9 @@ def test_forced_decoder_ids_and_suppress_lists_token_ids_exact(setup, pn, name, 
                            suppress_tokens=g["suppress"].tolist(), begin_suppress_tokens=g["begin_suppress"].tolist(),
                            forced_decoder_ids=forced, begin_index=prompt.shape[1] + forced[-1][0], **kw, **extra)
         if name == "beam5_rp":
-            check_beam(gen, out, g[f"{pn}.{name}"], g[f"{pn}.beam5_rp_scores"], dims.pad_id)
+            hy = load_hyps("tiny_forced")
+            check_beam(gen, out, g[f"{pn}.{name}"], g[f"{pn}.beam5_rp_scores"], dims.pad_id, hy[f"{pn}.{name}_hyps"],
+                       hy[f"{pn}.{name}_hyp_scores"])
         else:
             check(out, g[f"{pn}.{name}"], dims.pad_id)
 
@@ -333,6 +360,7 @@ def test_token_ids_exact_at_273_channels_and_large_v2_width(dev, tag, name, nb, 
     out = gen.generate(torch.from_numpy(x).to(dev), torch.from_numpy(labels[:, :4].copy()).to(dev), num_beams=nb,
                        max_new_tokens=int(g["new_tokens"]), check_every=1, **kw)
     if nb > 1:
-        check_beam(gen, out, g[name], g[name + "_scores"], dims.pad_id)
+        hy = load_hyps(tag)
+        check_beam(gen, out, g[name], g[name + "_scores"], dims.pad_id, hy[name + "_hyps"], hy[name + "_hyp_scores"])
     else:
         check_greedy_up_to_fp16_ties(out, g[name], g[name + "_margin"], 4, dims.pad_id)

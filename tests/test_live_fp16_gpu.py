@@ -11,9 +11,9 @@ What is asserted:
     the fp32-golden bound of tests/test_engine_gpu.py is 1e-2), and the HIP path is no further from the object's fp32
     run than the live fp16 run is (factor 1.25; measured: HIP 6.2e-4 .. 7.8e-4, live fp16 6.5e-4 .. 8.1e-4);
   * loss within 2e-4 relative of the live fp16 loss (measured <= 4e-5);
-  * greedy ids: equal to the live fp16 generation wherever the LIVE run's own decision margin (processed top-1 minus
-    top-2 score of that step) exceeds the fp16 tie threshold; a row may leave the live run only AT a position whose
-    live margin is below it (everything before must match).
+  * greedy ids: equal to the live fp16 generation; a row may leave the live run only AT a position that NEITHER side
+    decides (top-1 minus top-2 processed score <= one fp16 spacing in the live run and in this path's own trace) and
+    only for the live run's runner-up token; at most one such row over three repetitions of a case.
 """
 import os
 
@@ -138,14 +138,26 @@ def _live_generate(model, dims, xd, prompt, new, **kw):
         o = generate(model, xd, **generate_kwargs(dims, prompt.clone(), new), output_scores=True,
                      return_dict_in_generate=True, **kw)
     seq = o.sequences
-    # processed scores per step -> the live run's own decision margin (greedy: row-wise top-1 minus top-2)
-    margins = torch.stack([s.float().topk(2, -1).values for s in o.scores], 1)   # (rows, steps, 2)
-    return seq, (margins[..., 0] - margins[..., 1])
+    # processed scores per step -> the live run's own decision margin (greedy: row-wise top-1 minus top-2) and its two candidates
+    top = [s.float().topk(2, -1) for s in o.scores]
+    vals = torch.stack([t.values for t in top], 1)          # (rows, steps, 2)
+    idx = torch.stack([t.indices for t in top], 1)
+    return seq, (vals[..., 0] - vals[..., 1]), idx
+
+
+REPEATS = 3
 
 
 @pytest.mark.parametrize("tag,dims,B", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("name,kw", [("greedy", {}), ("greedy_rp", dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
 def test_greedy_ids_vs_live_fp16(dev, tag, dims, B, name, kw):
+    """north_star: greedy token ids bit-identical to the reference.  Against the reference's OWN numerics (a live fp16 run on this box)
+    a row may leave it only at an undecided position, and VERDICT r4 #3(a) pins what "undecided" means from BOTH sides:
+      * the live run's own top-1 minus top-2 processed score there is at most one fp16 spacing (0.0039 at magnitude 4-8);
+      * the token this path chose IS the live run's runner-up of that step (not just any token);
+      * this path's own top-1 minus top-2 there is at most one fp16 spacing too (it did not decide that position clearly either);
+      * everything before the flip matches, and over REPEATS full repetitions of the case (the live side is not reproducible at a
+        tie: identical live runs report different minimum margins) at most ONE row leaves in total."""
     from neuspeech1_amd.generate import Generator
     model = _obj(dims, dev)
     gen = Generator(_engine(dims, dev))
@@ -154,25 +166,36 @@ def test_greedy_ids_vs_live_fp16(dev, tag, dims, B, name, kw):
     xd = torch.from_numpy(x).to(dev)
     prompt = torch.from_numpy(labels[:, :4].copy()).to(dev)
     new = 24
-    ref, margin = _live_generate(model, dims, xd, prompt, new, num_beams=1, **kw)
-    out = gen.generate(xd, prompt, num_beams=1, max_new_tokens=new, check_every=1, **kw)
-    got, ref = out.cpu().numpy(), ref.cpu().numpy()
     P = prompt.shape[1]
-    Lm = min(got.shape[1], ref.shape[1])
-    flips = []
-    for b in range(B):
-        neq = np.nonzero(got[b, :Lm] != ref[b, :Lm])[0]
-        if len(neq) == 0:
-            continue
-        p = int(neq[0])
-        m = float(margin[b, p - P])
-        assert p >= P and m < TIE, (tag, name, b, p, m, got[b].tolist(), ref[b].tolist())
-        flips.append((b, p, round(m, 4)))
-    print(f"\n[{tag}/{name}] rows {B}, rows leaving the live fp16 run at a sub-threshold margin: {flips}; "
-          f"min live margin {float(margin.min()):.4f}")
-    # north_star: greedy token ids bit-identical to the reference.  Against the reference's OWN numerics (this live fp16 run) a row may
-    # leave it only where the live run did not decide: its top two fp16 logits EQUAL or one fp16 spacing apart (0.0039 at magnitude 4-8).
-    # The live side is not reproducible there itself: two identical live runs on one box report different minimum margins (0.0098 /
-    # 0.0078 on base208, 0.0000 / 0.0020 on base273 with the repetition penalty), and in 1 of 8 full runs of round 4 a row left at a
-    # live margin of 0.002.  Anything above one spacing fails, and so does more than one such row.
-    assert all(m <= ONE_FP16_SPACING for _, _, m in flips) and len(flips) <= 1, flips
+    flips, min_margin = [], float("inf")
+    first = None
+    for rep in range(REPEATS):
+        ref, margin, cand = _live_generate(model, dims, xd, prompt, new, num_beams=1, **kw)
+        trace = []
+        out = gen.generate(xd, prompt, num_beams=1, max_new_tokens=new, check_every=1, trace=trace, **kw)
+        got, ref = out.cpu().numpy(), ref.cpu().numpy()
+        if first is None:
+            first = got
+        assert np.array_equal(got, first), "the HIP generation itself must be reproducible run to run"
+        min_margin = min(min_margin, float(margin.min()))
+        Lm = min(got.shape[1], ref.shape[1])
+        for b in range(B):
+            neq = np.nonzero(got[b, :Lm] != ref[b, :Lm])[0]
+            if len(neq) == 0:
+                continue
+            p = int(neq[0])
+            assert p >= P, (tag, name, b, p)
+            step = p - P
+            m_live = float(margin[b, step])
+            runner_up = int(cand[b, step, 1])
+            hv, hi = trace[step]
+            m_hip = float(hv[b, 0] - hv[b, 1])
+            ctx = (tag, name, rep, b, p, m_live, m_hip, got[b].tolist(), ref[b].tolist())
+            assert m_live <= ONE_FP16_SPACING, ctx                 # the live run did not decide this position
+            assert int(got[b, p]) == runner_up, ctx                 # ... and this path took the live run's second candidate
+            assert int(hi[b, 0]) == int(got[b, p]), ctx             # (the trace is of this very decision)
+            assert m_hip <= ONE_FP16_SPACING, ctx                   # ... at a margin that is sub-spacing on this side too
+            flips.append((rep, b, p, round(m_live, 4), round(m_hip, 4)))
+    print(f"\n[{tag}/{name}] rows {B} x {REPEATS} repetitions, rows leaving the live fp16 run (rep, row, pos, live margin, hip margin): "
+          f"{flips}; min live margin {min_margin:.4f}")
+    assert len(flips) <= 1, flips

@@ -194,3 +194,27 @@ def test_oracle_forced_decoder_ids_match_reference_generate():
             assert np.array_equal(O.beam_search(sd, xt, dims, prompt, 5, n, **kw).numpy(), g[pn + ".beam5"]), pn
     # the forced positions really are forced, and position 1 (None) is free
     assert (g["p1.greedy_rp"][:, 2] == forced[1][1]).all() and (g["p1.greedy_rp"][:, 3] == forced[2][1]).all()
+
+
+@pytest.mark.parametrize("tag,src", [("tiny", "tiny"), ("tiny_sb", "tiny_sb"), ("tiny_forced", "tiny_forced"), ("base208", "base208"),
+                                     ("base273", "base273"), ("lv2w", "lv2w")])
+def test_reference_hypotheses_files_belong_to_their_goldens(tag, src):
+    """decode_<tag>_hyps.npz (the reference object's top-num_beams finished hypotheses, tools/make_goldens.py hyps; VERDICT r4
+    #3b): hypothesis 0 is the golden's own row, scores are sorted and hypothesis 0 carries the golden's score -- the GPU tests
+    may then accept a beam row that left hypothesis 0 only if it IS one of these alternatives."""
+    g = np.load(os.path.join(G, f"decode_{src}.npz"))
+    h = np.load(os.path.join(G, f"decode_{tag}_hyps.npz"))
+    names = [k[:-5] for k in h.files if k.endswith("_hyps")]
+    assert names
+    for n in names:
+        hyps, sc = h[n + "_hyps"], h[n + "_hyp_scores"]
+        ref = g[n]
+        assert hyps.shape[:2] == sc.shape == (ref.shape[0], int(h["num_beams"]))
+        L = min(ref.shape[1], hyps.shape[2])
+        assert np.array_equal(hyps[:, 0, :L], ref[:, :L])
+        assert (np.diff(sc, axis=1) <= 1e-6).all()
+        if n + "_scores" in g.files:
+            np.testing.assert_allclose(sc[:, 0], g[n + "_scores"], atol=1e-5)
+        # distinct alternatives: no two hypotheses of a row are the same sequence
+        for b in range(hyps.shape[0]):
+            assert len({tuple(r) for r in hyps[b].tolist()}) == hyps.shape[1]

@@ -52,7 +52,7 @@ def main():
     from neuspeech1_amd.feed import SignalFeed
     from neuspeech1_amd.synthetic import SyntheticProcessor
     from neuspeech1_amd.weights import WhisperDims, make_state_dict
-    from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding
+    from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, worker_context
     from utils.reader import CustomDataset
     dev = torch.device("cuda:0")
     dims = WhisperDims(ch=args.ch)
@@ -84,7 +84,8 @@ def main():
             ds = CustomDataset(raw_signals=raw, **kw)
             idx = [i % args.files for i in range(args.batch * ((steps or args.steps) + 4))]
             return torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=args.batch, shuffle=False,
-                                               num_workers=workers, collate_fn=coll, pin_memory=not raw)
+                                               num_workers=workers, collate_fn=coll, pin_memory=not raw,
+                                               multiprocessing_context=worker_context(workers))
 
         # 1. producer rates alone (no training): host collator path, 0 and W workers; feed path
         for name, raw, w in (("host_path_1proc", False, 0), (f"host_path_{args.workers}workers", False, args.workers),

@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "neuspeech1_amd", "csrc")
 # the dominant training kernel (bench.py: DOMINANT) and what its tile arithmetic / epilogues are written in
 DOMINANT_SOURCES = ("ns_gemm_p8s.hip", "ns_gemm_p8.hip", "ns_gemm_epi.h")
+# ... plus the dispatch rule that decides WHICH launches make up the class (moving NS_P8S_MIN_TILES from 1024 to 700 changed
+# the class mix -- and with it the per-launch average -- without touching a hashed file): lines of ns_gemm.hip matching these patterns
+DOMINANT_DISPATCH = ("ns_gemm.hip", (r"#define\s+NS_P8S_MIN_TILES\s+\d+", r"const bool big = [^;]*;", r"const bool pers = [^;]*;"))
 # one decode step: what moves its bytes -- attention over the cross / self caches (ns_attn_fewq, ns_attn_decode: 79 % / 92 % of a
 # beam-5 / greedy step's HBM traffic) and the small-M projections
 DECODE_SOURCES = ("ns_decode.hip", "ns_gemm_smallm.hip")
@@ -27,6 +30,14 @@ def source_hash(files=DOMINANT_SOURCES) -> str:
     for f in files:
         with open(os.path.join(CSRC, f), encoding="utf-8") as fh:
             h.update(stripped(fh.read()).encode())
+    if files is DOMINANT_SOURCES:
+        name, pats = DOMINANT_DISPATCH
+        with open(os.path.join(CSRC, name), encoding="utf-8") as fh:
+            text = _COMMENT.sub(" ", fh.read())
+        for p in pats:
+            found = re.findall(p, text, re.S)
+            assert found, f"{name}: dispatch pattern {p!r} not found (tools/kernel_hash.py is out of date)"
+            h.update(stripped("".join(found)).encode())
     return h.hexdigest()[:16]
 
 

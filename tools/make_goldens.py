@@ -310,6 +310,62 @@ def decode_golden(dims, tag, B, new_tokens, eos_variants=(34, 630), sequence_bia
     print(f"decode_{tag}: greedy tail {g['greedy'][:, -4:].tolist()}")
 
 
+def decode_hyps_golden(dims, tag, B, new_tokens, eos_variants=(), src=None, sequence_bias=None, forced=False):
+    """the reference object's top-`num_beams` FINISHED hypotheses (ids + length-normalised scores) of every
+    beam-search golden, so that a beam row which leaves hypothesis 0 at an fp16 near-tie can be required to BE one of the
+    reference's own alternatives (evaluation.py:369-386 -> GenerationMixin.generate with num_return_sequences = num_beams).
+    Hypothesis 0 must reproduce the ids already stored in decode_<tag>.npz (asserted here).  -> decode_<tag>_hyps.npz"""
+    import transformers
+    sd_np = make_state_dict(dims, 42)
+    model = build_hf(dims, sd_np)
+    x, labels = synth_batch(dims, B, 1234)
+    feats = torch.from_numpy(x)
+    old = np.load(os.path.join(OUT, f"decode_{src or tag}.npz"))
+    gen = transformers.GenerationMixin.generate
+    nb = 5
+    g = {"B": B, "new_tokens": new_tokens, "num_beams": nb}
+
+    def run(name, prompt, **kw):
+        common = dict(do_sample=False, max_new_tokens=new_tokens, decoder_input_ids=prompt, suppress_tokens=None,
+                      begin_suppress_tokens=None, pad_token_id=dims.pad_id, eos_token_id=dims.eos_id,
+                      return_dict_in_generate=True, output_scores=True, num_beams=nb, num_return_sequences=nb)
+        common.update(kw)
+        with torch.no_grad():
+            o = gen(model, feats, **common)
+        seqs = o.sequences.numpy().reshape(B, nb, -1)
+        sc = o.sequences_scores.numpy().astype(np.float32).reshape(B, nb)
+        ref = old[name]
+        Lm = min(ref.shape[1], seqs.shape[2])
+        assert np.array_equal(seqs[:, 0, :Lm], ref[:, :Lm]), (name, seqs[:, 0].tolist(), ref.tolist())
+        g[name + "_hyps"], g[name + "_hyp_scores"] = seqs, sc
+        print(f"decode_{tag}_hyps {name}: scores row 0 {sc[0].round(4).tolist()}")
+
+    rp = dict(repetition_penalty=5.0, no_repeat_ngram_size=2)
+    if forced:
+        from transformers import LogitsProcessorList
+        from transformers.generation.logits_process import SuppressTokensAtBeginLogitsProcessor
+        fz = [[int(i), None if int(t) < 0 else int(t)] for i, t in zip(old["forced_idx"], old["forced_tok"])]
+        for pname in ("p1", "p4"):
+            prompt = torch.from_numpy(old[pname + ".prompt"])
+            P = prompt.shape[1]
+            mk = lambda: LogitsProcessorList([SuppressTokensAtBeginLogitsProcessor(old["begin_suppress"].tolist(), P + fz[-1][0]),  # noqa: E731
+                                              _ForceTokens(fz)])
+            run(f"{pname}.beam5_rp", prompt, suppress_tokens=old["suppress"].tolist(), logits_processor=mk(), **rp)
+            run(f"{pname}.beam5", prompt, suppress_tokens=old["suppress"].tolist(), logits_processor=mk())
+    else:
+        prompt = torch.from_numpy(labels[:, :4].copy())
+        sfx = ""
+        extra = {}
+        if sequence_bias is not None:
+            sfx, extra = "_sb", dict(sequence_bias=dict(sequence_bias))
+        run("beam5_rp" + sfx, prompt, **rp, **extra)
+        run("beam5" + sfx, prompt, **extra)
+        for eos in eos_variants:
+            run(f"beam5_eos{eos}", prompt, eos_token_id=eos)
+            run(f"beam5_rp_eos{eos}", prompt, eos_token_id=eos, **rp)
+    np.savez_compressed(os.path.join(OUT, f"decode_{tag}_hyps.npz"), **g)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -353,6 +409,16 @@ if __name__ == "__main__":
         lora_oracle_golden(WHISPER_LARGE_V2, "lv2", B=1)
     if "forced" in what:
         decode_forced_golden(TINY, "tiny", B=3, new_tokens=20)
+    if "hyps" in what:
+        # top-num_beams finished hypotheses of every beam golden (decode_*_hyps.npz)
+        decode_hyps_golden(TINY, "tiny", B=3, new_tokens=24, eos_variants=(34, 630))
+        sbg = np.load(os.path.join(OUT, "decode_tiny_sb.npz"))
+        sb = {tuple(int(t) for t in str(k).split(",")): float(v) for k, v in zip(sbg["sequence_bias_keys"], sbg["sequence_bias_vals"])}
+        decode_hyps_golden(TINY, "tiny_sb", B=3, new_tokens=24, sequence_bias=sb)
+        decode_hyps_golden(TINY, "tiny_forced", B=3, new_tokens=20, forced=True)
+        decode_hyps_golden(WHISPER_BASE, "base208", B=2, new_tokens=16)
+        decode_hyps_golden(WhisperDims(ch=273), "base273", B=2, new_tokens=16)
+        decode_hyps_golden(LV2W, "lv2w", B=2, new_tokens=12)
     if "hf_ckpt" in what:
         hf_checkpoint_golden(TINY, "tiny", B=2)
 

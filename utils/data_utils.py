@@ -5,8 +5,6 @@ import string
 from dataclasses import dataclass
 from typing import Any, Dict, List, Union
 
-import gc
-
 import numpy as np
 import torch
 
@@ -83,21 +81,46 @@ class DataCollatorSpeechSeq2SeqWithPadding:
 DataCollatorOnlySpeechSeq2SeqWithPadding = DataCollatorSpeechSeq2SeqWithPadding
 
 
+_PRELOAD = ["numpy", "torch", "torch.utils.data", "transformers", "utils.reader", "utils.data_utils", "neuspeech1_amd.feed",
+            "neuspeech1_amd.synthetic"]
+
+
+def worker_context(num_workers: int):
+    """`multiprocessing_context` for every DataLoader of the CLIs (reference worker processes: finetune.py:249,
+    evaluation.py:126-127): a FORKSERVER.
+
+    The workers must never be forked from the process that drives the GPU: a forked child inherits the parent's HIP objects,
+    and ANY destructor that runs there (cyclic garbage the parent had not collected yet, an exception unwinding, interpreter
+    shut-down) is a HIP call in a forked process -- segfaulting DataLoader workers in round 4, papered over with
+    gc.collect() + gc.freeze() around the fork, which covers cyclic garbage only.  With a forkserver the workers are forked
+    from a helper process that was started fresh (`spawn`: no HIP state, no GPU memory mappings) and has only imported the
+    modules in _PRELOAD, so a worker starts in milliseconds and can never see a HIP object.  Dataset, collator and sampler
+    travel by pickle.  Returns None for num_workers == 0 (DataLoader's in-process path)."""
+    if num_workers <= 0:
+        return None
+    import multiprocessing as mp
+    ctx = mp.get_context("forkserver")
+    start_worker_server()
+    return ctx
+
+
+def start_worker_server():
+    """start the forkserver (idempotent).  The CLIs call this FIRST, before the model touches the GPU: the helper is a fresh
+    child process either way, but started early its imports (_PRELOAD, ~3 s) overlap the model load instead of the first batch."""
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    import importlib.util
+    mp.set_forkserver_preload([m for m in _PRELOAD if importlib.util.find_spec(m.split(".")[0]) is not None])
+    forkserver.ensure_running()
+
+
 def fork_safe_iter(loader):
-    """iter(loader) for a DataLoader whose workers are FORKED from a process that holds HIP objects.
-
-    A forked child must not run a HIP call.  The workers' own code does not -- but their cyclic garbage collector may: garbage the parent
-    has not collected yet (a closed feed's staging slots with their events and streams, a finished generator's graph objects) is garbage
-    in the child too, and the first collection there runs the destructors, i.e. hipEventDestroy / hipStreamDestroy in a forked process:
-    a segmentation fault in a DataLoader worker, depending on allocation counts (seen in round 4 when a shape change moved the collector's
-    threshold).  Collect in the parent first, then freeze what is left for the duration of the fork (gc.freeze() exists for this: the
-    children inherit the frozen generation and never look at it)."""
+    """iter(loader).  Kept as the one place the CLIs start their workers: a loader with workers must have been built with
+    `multiprocessing_context=worker_context(n)` -- forking them from this (GPU-driving) process is refused."""
     if getattr(loader, "num_workers", 0) > 0:
-        gc.collect()
-        gc.freeze()
-        try:
-            return iter(loader)      # _MultiProcessingDataLoaderIter starts (forks) its workers here
-        finally:
-            gc.unfreeze()
+        ctx = getattr(loader, "multiprocessing_context", None)
+        method = ctx.get_start_method() if ctx is not None else None
+        if method not in ("forkserver", "spawn"):
+            raise RuntimeError("DataLoader workers must come from utils.data_utils.worker_context() (forkserver), never from a fork "
+                               f"of the process that holds the GPU (start method: {method or 'fork (default)'})")
     return iter(loader)
-
