@@ -356,8 +356,11 @@ typedef struct {
   int64_t kv_group_stride, kv_pos_stride;
   /* optional append (anc layout, nq == 1): Knew / Vnew = this step's key / value rows (row r at r*ldnew, head h at
    * h*64) -- position Lk-1 is read from them and also written into the cache row (Lk-1)*kv_pos_stride + r, so the
-   * decode loop needs no separate cache-update launch (utils/load_model.py:1332-1351 keeps past_key_values). */
-  const void *Knew, *Vnew; int32_t ldnew, reserved;
+   * decode loop needs no separate cache-update launch (utils/load_model.py:1332-1351 keeps past_key_values).
+   * slot0 (ABI 3; the field was `reserved`, always 0): the append writes cache slot slot0 + r.  A caller that runs a ROW RANGE
+   * [slot0, slot0 + groups) of the batch as a launch of its own (the decode loop's half-batches on two streams) offsets Q / O /
+   * anc / Knew / Vnew itself and leaves K / V -- which `anc` indexes by global slot -- at their base. */
+  const void *Knew, *Vnew; int32_t ldnew, slot0;
 } ns_attn_decode_desc;
 int ns_attn_decode(const ns_attn_decode_desc* d, void* stream);
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
   const half_t* const Kn = p.Knew ? (const half_t*)p.Knew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
   const half_t* const Vn = p.Knew ? (const half_t*)p.Vnew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
   if (Kn && sg == 0) {
-    const long long r = (long long)(Lk - 1) * p.kv_pos_stride + grp;
+    const long long r = (long long)(Lk - 1) * p.kv_pos_stride + p.slot0 + grp;
     *(half8*)((half_t*)p.K + h * D + l8 * 8 + r * p.ldk) = *(const half8*)Kn;
     *(half8*)((half_t*)p.V + h * D + l8 * 8 + r * p.ldv) = *(const half8*)Vn;
   }
@@ -955,6 +955,7 @@ extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
                "ns_attn_decode: bad shape nq=%d groups=%d Lk=%d Lk_max=%d", d->nq, d->groups, d->Lk, d->Lk_max);
   NS_CHECK_ARG(!d->anc || d->nq == 1, "ns_attn_decode: ancestry indirection needs nq == 1");
   NS_CHECK_ARG(!d->Knew || (d->Vnew && d->anc && d->nq == 1 && d->ldnew % 8 == 0), "ns_attn_decode: append needs Vnew, the ancestry layout, nq == 1 and ldnew % 8 == 0");
+  NS_CHECK_ARG(d->slot0 >= 0 && (d->slot0 == 0 || d->Knew), "ns_attn_decode: slot0 is the append's slot offset (needs Knew; >= 0)");
   NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0, "ns_attn_decode: strides must be multiples of 8");
   dim3 grid(d->groups, d->H);
   hipStream_t st = (hipStream_t)stream;

@@ -73,6 +73,7 @@ class Generator:
         # beam-5), so only generations with >= 128 steps left (whisper's max_length is 448) capture
         import os
         self.graph_min_steps = int(os.environ.get("NS_GRAPH_MIN_STEPS", 128)) if graph_min_steps is None else graph_min_steps
+        self.split_graph_min_steps = int(os.environ.get("NS_SPLIT_GRAPH_MIN_STEPS", 16))
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
@@ -138,6 +139,55 @@ class Generator:
         fused_select = Vp <= ops.SELECT_MAX_LDV and os.environ.get("NS_NO_FUSED_SELECT") != "1"
         scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
 
+        # Row ranges of the batch as independent chains on separate streams: a decode step is a serial chain in
+        # which the HBM-bound cross-attention (393 MB per layer at B = 128, ~5.5 TB/s) and the latency-bound small-M projections /
+        # LayerNorms (a few hundred CUs' worth of work at best) alternate, each leaving the other resource idle.  With the
+        # sequences cut into `nsplit` ranges that run the six layers on a stream each, one range streams its cross K/V while the
+        # others are in their projection chains.  Every kernel is row-independent (a row's results do not depend on which other
+        # rows share its launch, as long as the same kernel is dispatched), the ranges join before the final LayerNorm / LM head /
+        # selection.  NS_DECODE_SPLIT overrides (1 = one chain).
+        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or (2 if B >= 32 else 1)
+        nsplit = max(1, min(nsplit, B))
+        cuts = [B * k // nsplit for k in range(nsplit + 1)]
+        side = [torch.cuda.Stream(dev) for _ in range(nsplit - 1)] if dev.type == "cuda" else []
+        self.last_split = nsplit
+
+        def layers(s0: int, s1: int, t: int, a, c1):
+            """the decoder layers for sequences [s0, s1) = rows [s0 * nb, s1 * nb); results in h[0] / h[1] by layer-count parity"""
+            r0, r1 = s0 * nb, s1 * nb
+            n = r1 - r0
+            hh = [h[0][r0:r1], h[1][r0:r1]]
+            x_, qkv_, qc_, ao_, gf_ = x16[r0:r1], qkv[r0:r1], qc[r0:r1], ao[r0:r1], gf[r0:r1]
+            st_ = (st[0][r0:r1], st[1][r0:r1])
+            for li, Lw in enumerate(eng.dec):
+                ops.layernorm_fwd(hh[0], *Lw["ln1"], x_, *st_, n, d)
+                eng._lin(x_, n, Lw["qkv"], C16=qkv_)
+                # the kernel reads position t from this step's k | v rows and appends them to the cache itself
+                ops.attn_decode(Q=qkv_, K=kvc[li], V=(kvc[li], d), O=ao_, groups=n, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
+                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a[r0:r1], anc_ld=max_len, kv_pos_stride=Bp,
+                                kv_len_dev=c1, Knew=(qkv_, d), Vnew=(qkv_, 2 * d), ldnew=3 * d, slot0=r0)
+                eng._lin(ao_, n, Lw["out"], R32=hh[0], H32=hh[1])
+                ops.layernorm_fwd(hh[1], *Lw["ln2"], x_, *st_, n, d)
+                eng._lin(x_, n, Lw["cq"], C16=qc_)
+                kx = kvx[li][s0 * S:s1 * S]
+                if fewq:
+                    ops.attn_fewq(Q=qc_, K=kx, Vt=vtx[li][s0:s1], O=ao_, groups=s1 - s0, nq=nb, H=H, Lk=S, ldq=d, ldk=2 * d,
+                                  ldvt=Sp, ldo=d)
+                elif nb > 1:
+                    # beams of a sequence = the "queries" of one flash-attention problem over the sequence's encoder
+                    # K/V: the MFMA kernel reads the 384 KB per (sequence, head) once and is HBM-bound (~60 us / layer
+                    # at B = 128), where the per-key VALU dot products of ns_attn_decode took 108 us at 5 beams
+                    ops.attn_fwd(Q=qc_, K=kx, V=(kx, d), O=ao_, B=s1 - s0, H=H, Lq=nb, Lk=S, ldq=d, ldk=2 * d,
+                                 ldv=2 * d, ldo=d, causal=False)
+                else:
+                    ops.attn_decode(Q=qc_, K=kx, V=(kx, d), O=ao_, groups=s1 - s0, nq=nb, H=H, Lk=S, Lk_max=S, ldq=d,
+                                    ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
+                eng._lin(ao_, n, Lw["cout"], R32=hh[1], H32=hh[0])
+                ops.layernorm_fwd(hh[0], *Lw["ln3"], x_, *st_, n, d)
+                eng._lin(x_, n, Lw["fc1"], G16=gf_, gelu=True)     # (no pre-activation copy: nothing reads it without a backward)
+                eng._lin(gf_, n, Lw["fc2"], R32=hh[0], H32=hh[1])
+                hh.reverse()
+
         def step(tok: torch.Tensor, t: int, parent, ctr=None):
             """Feed token `tok` (Bp,) at position t; leaves last-position logits in `logits`.
             With `ctr` (device int32 [t, t+1]) the position is read on the device."""
@@ -147,32 +197,18 @@ class Generator:
             anc.reverse()
             a = anc[0]
             ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t, pos0_dev=c0)
-            for li, Lw in enumerate(eng.dec):
-                ops.layernorm_fwd(h[0], *Lw["ln1"], x16, *st, Bp, d)
-                eng._lin(x16, Bp, Lw["qkv"], C16=qkv)
-                # the kernel reads position t from this step's k | v rows and appends them to the cache itself
-                ops.attn_decode(Q=qkv, K=kvc[li], V=(kvc[li], d), O=ao, groups=Bp, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
-                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a, anc_ld=max_len, kv_pos_stride=Bp,
-                                kv_len_dev=c1, Knew=(qkv, d), Vnew=(qkv, 2 * d), ldnew=3 * d)
-                eng._lin(ao, Bp, Lw["out"], R32=h[0], H32=h[1])
-                ops.layernorm_fwd(h[1], *Lw["ln2"], x16, *st, Bp, d)
-                eng._lin(x16, Bp, Lw["cq"], C16=qc)
-                if fewq:
-                    ops.attn_fewq(Q=qc, K=kvx[li], Vt=vtx[li], O=ao, groups=B, nq=nb, H=H, Lk=S, ldq=d, ldk=2 * d,
-                                  ldvt=Sp, ldo=d)
-                elif nb > 1:
-                    # beams of a sequence = the "queries" of one flash-attention problem over the sequence's encoder
-                    # K/V: the MFMA kernel reads the 384 KB per (sequence, head) once and is HBM-bound (~60 us / layer
-                    # at B = 128), where the per-key VALU dot products of ns_attn_decode took 108 us at 5 beams
-                    ops.attn_fwd(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, B=B, H=H, Lq=nb, Lk=S, ldq=d, ldk=2 * d,
-                                 ldv=2 * d, ldo=d, causal=False)
-                else:
-                    ops.attn_decode(Q=qc, K=kvx[li], V=(kvx[li], d), O=ao, groups=B, nq=nb, H=H, Lk=S, Lk_max=S, ldq=d,
-                                    ldk=2 * d, ldv=2 * d, ldo=d, kv_group_stride=S)
-                eng._lin(ao, Bp, Lw["cout"], R32=h[1], H32=h[0])
-                ops.layernorm_fwd(h[0], *Lw["ln3"], x16, *st, Bp, d)
-                eng._lin(x16, Bp, Lw["fc1"], G16=gf, gelu=True)     # (no pre-activation copy: nothing reads it without a backward)
-                eng._lin(gf, Bp, Lw["fc2"], R32=h[0], H32=h[1])
+            if nsplit == 1:
+                layers(0, B, t, a, c1)
+            else:
+                main = torch.cuda.current_stream()
+                for k, sd in enumerate(side):       # fork: every range starts behind the embedding
+                    sd.wait_stream(main)
+                    with torch.cuda.stream(sd):
+                        layers(cuts[k + 1], cuts[k + 2], t, a, c1)
+                layers(cuts[0], cuts[1], t, a, c1)
+                for sd in side:                     # join
+                    main.wait_stream(sd)
+            if len(eng.dec) % 2:
                 h.reverse()
             ops.layernorm_fwd(h[0], *eng.dec_ln, x16, *st, Bp, d)
             ops.gemm(A=x16, am=rowmap(d), K=d, B=eng.E16, ldb=d, M=Bp, N=Vp, C16=logits, c16m=rowmap(Vp))
@@ -238,7 +274,10 @@ class Generator:
                         break
                 if graphs is None:
                     step(next_tok, cur - 1, parent)
-                    if graph_ok and max_len - cur >= self.graph_min_steps:
+                    # two chains per step double the launches the host has to enqueue (~150 per step against ~0.6 ms of GPU time):
+                    # with split chains the replayed graph is what keeps the loop GPU-bound, so even short generations capture
+                    gms = self.graph_min_steps if nsplit == 1 else min(self.graph_min_steps, self.split_graph_min_steps)
+                    if graph_ok and max_len - cur >= gms:
                         # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
                         ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
                         graphs = []

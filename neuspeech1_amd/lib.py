@@ -118,7 +118,7 @@ class AttnDecodeDesc(C.Structure):
         ("head_dim", C.c_int32),
         ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("anc_ld", C.c_int32),
         ("kv_group_stride", C.c_int64), ("kv_pos_stride", C.c_int64),
-        ("Knew", C.c_void_p), ("Vnew", C.c_void_p), ("ldnew", C.c_int32), ("reserved", C.c_int32),
+        ("Knew", C.c_void_p), ("Vnew", C.c_void_p), ("ldnew", C.c_int32), ("slot0", C.c_int32),
     ]
 
 

@@ -231,14 +231,14 @@ def cast_jobs(table: torch.Tensor, njobs: int):
 
 # ----------------------------------------------------------------------------- decode loop
 def attn_decode(*, Q, K, V, O, groups, nq, H, Lk, Lk_max, ldq, ldk, ldv, ldo, anc=None, anc_ld=0, kv_group_stride=0,
-                kv_pos_stride=0, kv_len_dev=None, Knew=None, Vnew=None, ldnew=0):
+                kv_pos_stride=0, kv_len_dev=None, Knew=None, Vnew=None, ldnew=0, slot0=0):
     d = L.AttnDecodeDesc()
     d.Q, d.K, d.V, d.O = ptr(Q), ptr(K), ptr(V), ptr(O)
     d.anc, d.kv_len_dev = ptr(anc), ptr(kv_len_dev)
     d.groups, d.nq, d.H, d.Lk, d.Lk_max, d.head_dim = groups, nq, H, Lk, Lk_max, 64
     d.ldq, d.ldk, d.ldv, d.ldo, d.anc_ld = ldq, ldk, ldv, ldo, anc_ld
     d.kv_group_stride, d.kv_pos_stride = kv_group_stride, kv_pos_stride
-    d.Knew, d.Vnew, d.ldnew = ptr(Knew), ptr(Vnew), ldnew
+    d.Knew, d.Vnew, d.ldnew, d.slot0 = ptr(Knew), ptr(Vnew), ldnew, slot0
     L.check(L.load().ns_attn_decode(C.byref(d), _stream()), "ns_attn_decode")
 
 

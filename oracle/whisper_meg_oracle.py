@@ -379,6 +379,56 @@ def beam_search(sd, x, dims, prompt, num_beams, max_new_tokens, repetition_penal
     return fin_seqs[:, 0]
 
 
+def sequence_bias_(scores, ids, sequence_bias):
+    """HF:generation/logits_process.py SequenceBiasLogitsProcessor (FIRST in HF's processor order; the reference passes a table
+    through model.generate(sequence_bias=...), evaluation.py:362-364): a length-1 entry adds its bias to its token everywhere;
+    a longer entry adds its bias to its LAST token in every row whose history ends with the tokens before it."""
+    Bn, cur = ids.shape
+    for toks, bias in sequence_bias.items():
+        toks = tuple(int(t) for t in toks)
+        if len(toks) == 1:
+            scores[:, toks[0]] += bias
+        elif len(toks) - 1 <= cur:
+            pre = torch.tensor(toks[:-1], dtype=ids.dtype)
+            hit = (ids[:, cur - len(pre):] == pre).all(1)
+            scores[hit, toks[-1]] += bias
+    return scores
+
+
+def sequence_score(sd, x, dims, seq, prompt_len, repetition_penalty=1.0, no_repeat_ngram_size=0, suppress_tokens=(),
+                   begin_suppress_tokens=(), length_penalty=1.0, eos_id=None, forced_decoder_ids=None, sequence_bias=None):
+    """The score HF's beam search (HF:generation/utils.py:3208-3545; beam_search above) assigns to ONE given hypothesis, in fp32:
+    the sum of the PROCESSED log-probabilities of its generated tokens (log_softmax -> sequence bias -> repetition penalty ->
+    no-repeat-ngram -> suppress lists -> forced ids, each on the prefix before the token) / generated_length ** length_penalty,
+    where a hypothesis ends at its first EOS after the prompt (else at the row's end).  x (1, ch, T), seq (L,) prompt + tokens
+    (+ pad).  The GPU tests hold a beam row that left the reference's best hypothesis against this: a valid alternative scores
+    within fp16 resolution of the best under the REFERENCE arithmetic, whatever the path under test computed for it."""
+    eos_id = dims.eos_id if eos_id is None else eos_id
+    seq = torch.as_tensor(seq, dtype=torch.long).view(1, -1)
+    P = int(prompt_len)
+    gen = seq[0, P:]
+    is_eos = (gen == eos_id).nonzero()
+    end = P + (int(is_eos[0]) + 1 if len(is_eos) else gen.numel())
+    enc = encoder(sd, x, dims)
+    hid = decoder(sd, seq[:, :end - 1], enc, dims)
+    logits = F.linear(hid[0], sd["model.decoder.embed_tokens.weight"]).float()        # row t predicts token t + 1
+    begin = begin_index_for(P, forced_decoder_ids)
+    total = 0.0
+    for cur in range(P, end):
+        lp = F.log_softmax(logits[cur - 1:cur], -1).clone()
+        ids = seq[:, :cur]
+        if sequence_bias:
+            sequence_bias_(lp, ids, sequence_bias)
+        if repetition_penalty != 1.0:
+            repetition_penalty_(lp, ids, repetition_penalty)
+        if no_repeat_ngram_size > 0:
+            no_repeat_ngram_(lp, ids, no_repeat_ngram_size)
+        suppress_(lp, list(suppress_tokens), list(begin_suppress_tokens), cur, begin)
+        force_tokens_(lp, forced_decoder_ids, cur)
+        total += float(lp[0, int(seq[0, cur])])
+    return total / float(end - P) ** length_penalty
+
+
 # --------------------------------------------------------------------------- data feed
 def reader_pad_sample(sample: np.ndarray, dataset_name: str | None, modal_ch: int, max_len: int) -> np.ndarray:
     """utils/reader.py:272-280 (dataset-specific channel slice, channel zero-pad) + :496-506 (time crop / right zero-pad)."""

@@ -98,7 +98,12 @@ def test_b128_273ch_decode_rows_equal_golden_and_small_batch_decodes(dev, name, 
             if row_is(hyps[b, 0]):
                 continue
             alt = [k for k in range(1, hyps.shape[1]) if row_is(hyps[b, k])]
-            assert alt and hsc[b, 0] - hsc[b, alt[0]] < 2e-2, (b, out[b].tolist(), hyps[b].tolist(), hsc[b].tolist())
+            if alt:
+                assert hsc[b, 0] - hsc[b, alt[0]] < 2e-2, (b, out[b].tolist(), hyps[b].tolist(), hsc[b].tolist())
+            else:       # outside the reference's final five: the reference's own arithmetic (oracle rescoring) must rate it a near-tie
+                from tests.test_generate_gpu import make_rescore
+                true = make_rescore(dims, torch.from_numpy(x2), 4, **kw)(b, out[b])
+                assert abs(true - float(hsc[b, 0])) < 2e-2 and abs(true - float(scores[b])) < 2e-2, (b, true, scores[b], hsc[b].tolist())
             left += 1
         assert left <= 1
     # every row against the SAME input decoded in a batch of two

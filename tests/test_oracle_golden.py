@@ -218,3 +218,27 @@ def test_reference_hypotheses_files_belong_to_their_goldens(tag, src):
         # distinct alternatives: no two hypotheses of a row are the same sequence
         for b in range(hyps.shape[0]):
             assert len({tuple(r) for r in hyps[b].tolist()}) == hyps.shape[1]
+
+
+def test_oracle_sequence_score_reproduces_the_reference_hypothesis_scores():
+    """O.sequence_score (what the GPU beam tests rescore a row with when it left the reference's best hypothesis) against the
+    reference object's own `sequences_scores` of ALL its finished hypotheses: plain, with repetition penalty + no-repeat-2,
+    with EOS-finished rows, and with a sequence-bias table."""
+    dims = TINY
+    sd = O.to_torch(make_state_dict(dims, 42))
+    x, labels = synth_batch(dims, 3, 1234)
+    xt = torch.from_numpy(x)
+    rp = dict(repetition_penalty=5.0, no_repeat_ngram_size=2)
+    h = np.load(os.path.join(G, "decode_tiny_hyps.npz"))
+    hs = np.load(os.path.join(G, "decode_tiny_sb_hyps.npz"))
+    sbg = np.load(os.path.join(G, "decode_tiny_sb.npz"))
+    sb = {tuple(int(t) for t in str(k).split(",")): float(v) for k, v in zip(sbg["sequence_bias_keys"], sbg["sequence_bias_vals"])}
+    cases = [(h, "beam5", {}), (h, "beam5_rp", rp), (h, "beam5_eos630", dict(eos_id=630)), (h, "beam5_rp_eos34", dict(eos_id=34, **rp)),
+             (hs, "beam5_rp_sb", dict(sequence_bias=sb, **rp)), (hs, "beam5_sb", dict(sequence_bias=sb))]
+    with torch.no_grad():
+        for f, name, kw in cases:
+            hyps, sc = f[name + "_hyps"], f[name + "_hyp_scores"]
+            for b in range(hyps.shape[0]):
+                for k in (0, 2, 4):
+                    got = O.sequence_score(sd, xt[b:b + 1], dims, hyps[b, k], 4, **kw)
+                    assert abs(got - float(sc[b, k])) < 2e-4, (name, b, k, got, float(sc[b, k]))
