@@ -136,6 +136,25 @@ int ns_gemm(const ns_gemm_desc* d, void* stream);
 int ns_gemm_side_supported(int M, int N, int K);
 /* u16[m][j] = round16(alpha * sum_t slabs[t][m][j]),  t < tiles, j < 32 */
 int ns_gemm_side_reduce(const float* slabs, int tiles, int M, float alpha, void* u16, int ldu, void* stream);
+/* ------------------------------------------------------------------------
+ * ns_gemm_ln: a residual Linear with N = 512 output columns and the LayerNorm that reads its result, in one launch
+ * (HF:modeling_whisper.py:354 out_proj / :405 fc2 -> :394,:407 residual add -> :402 final_layer_norm / :392 the next layer's
+ * self_attn_layer_norm / utils/load_model.py:468 encoder.layer_norm):
+ *     H32 = R32 + round16(A W^T (+ A2 B2^T) + bias);   x16 = LN(H32) * gamma + beta;   mean / rstd saved for the backward.
+ * `g` describes the Linear exactly as for ns_gemm (NT form; A, am, K, B, bias, the optional second product, R32, H32, h32m, alpha)
+ * with N = 512 and nothing else set; H32, x16, mean and rstd are bitwise what ns_gemm followed by ns_layernorm_fwd produce.
+ * A workgroup owns complete rows, so H32 is not read back and A is read once (csrc/ns_gemm_rowln.hip).
+ * ns_gemm_ln_supported: N == 512, K % 64 == 0, K2 in {0, 16, 32}, M >= 1024.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  ns_gemm_desc g;
+  const float* gamma; const float* beta;
+  float eps; int32_t ldx;                 /* ldx: row stride of x16 (elements) */
+  void* x16; float* mean; float* rstd;    /* mean / rstd may be NULL (inference) */
+} ns_gemm_ln_desc;
+int ns_gemm_ln_supported(int M, int N, int K, int K2);
+int ns_gemm_ln(const ns_gemm_ln_desc* d, void* stream);
+
 /* A/B knob for benchmarks: 1 (default) = automatic kernel choice, 0 = register-staged kernel only; 2..5 force one of
  * the wide NT kernels (see ns_gemm.hip), 6 = automatic without the small-M split-K kernel */
 void ns_debug_set_ring(int on);

@@ -209,6 +209,9 @@ class MegWhisperEngine:
         # Infinity Cache (the LayerNorm input was just written) and the one-workgroup-per-CU fused kernel takes 68 / 77 us against
         # 24 + 25 / 24 + 33 us (profiles/r4_a_bench_kernel_stats.csv).  NS_LN_LORA=1 turns it on.
         self.no_ln_lora = os.environ.get("NS_LN_LORA") != "1"
+        # residual Linear + the LayerNorm that reads its result in one launch (ns_gemm_ln: d = 512, bitwise the two launches' results);
+        # NS_ROWLN=0 keeps ns_gemm + ns_layernorm_fwd (A/B runs)
+        self.use_rowln = os.environ.get("NS_ROWLN", "1") != "0"
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
@@ -702,25 +705,41 @@ class MegWhisperEngine:
                  pos_rows=S, flags=GELU_FWD)
         dp = self._drop_p()
         rank = r
+
+        def fuse_ln_at(i):
+            """LayerNorm + the adapter bottleneck of the Linear it feeds in ONE pass (ns_layernorm_fwd_lora; NS_LN_LORA=1, off by default)"""
+            ri = rank if i < self.n_lora else 0
+            return bool(ri) and not self.no_ln_lora and ops.layernorm_fwd_lora_supported(M, d, 3 * ri) and \
+                ops.layernorm_fwd_lora_supported(M, d, ri)
+
+        def lin_ln(x16, lin, R32, H32, ln, xout, st, A2=None, lda2=0, K2=0, B2=None):
+            """residual Linear + the LayerNorm that reads its result: one launch (ns_gemm_ln, bitwise the pair's results) where built"""
+            if self.use_rowln and ops.gemm_ln_supported(M, lin.N, lin.K, K2):
+                ops.gemm_ln(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, A2=A2,
+                            am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
+                            R32=R32, H32=H32, h32m=rowmap(lin.N), gamma=ln[0], beta=ln[1], x16=xout, ldx=d, mean=st[0], rstd=st[1])
+                return
+            self._lin(x16, M, lin, R32=R32, H32=H32, A2=A2, lda2=lda2, K2=K2, B2=B2)
+            ops.layernorm_fwd(H32, *ln, xout, *st, M, d)
+
+        ne = dims.enc_layers
+        ln1_done = final_done = False
         for i, Lw in enumerate(self.enc):
             r = rank if i < self.n_lora else 0     # --fine_tune_layers: only the first n_lora layers carry adapters
             j = i if train else 0
-            hin = h[2 * i] if train else h[i % 2 * 0 + (0 if i % 2 == 0 else 1)]
             if train:
                 hin, hmid, hout = h[2 * i], h[2 * i + 1], h[2 * i + 2]
             else:
                 hin, hmid, hout = h[0], h[1], h[0]
             lo = self.lora_ops[i] if r else None
             seed = self._layer_seed(i)
-            # LayerNorm and the adapter bottleneck of the Linear it feeds in ONE pass over the residual stream where the fused
-            # kernel is built (ns_layernorm_fwd_lora: u bitwise equal to the separate down-projection launch)
-            fuse_ln = bool(r) and not self.no_ln_lora and ops.layernorm_fwd_lora_supported(M, d, 3 * r) and \
-                ops.layernorm_fwd_lora_supported(M, d, r)
+            fuse_ln = fuse_ln_at(i)
             if fuse_ln:
                 ops.layernorm_fwd_lora(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d, lo["Aqkv"], d, 3 * r, b["uqkv"][j], 3 * r,
                                        alpha=self._drop_inv(), drop_p=dp, drop_seed=seed, seed_dev=self.seed_ctr if dp > 0 else None)
-            else:
+            elif not ln1_done:      # (the previous layer's fc2 launch normalised this layer's input already)
                 ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
+            ln1_done = False
             if r:
                 if not fuse_ln:
                     self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
@@ -732,17 +751,30 @@ class MegWhisperEngine:
             qkv = b["qkv"][j]
             ops.attn_fwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][j], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
                          ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j])
+            ad = dict(A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"]) if r else {}
             if r:
                 self._gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 1)
-                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"])
-            else:
-                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid)
             if fuse_ln:
+                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, **ad)
                 ops.layernorm_fwd_lora(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d, lo["fc1_A"], d, r, b["u1"][j], r,
                                        alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2, seed_dev=self.seed_ctr if dp > 0 else None)
             else:
-                ops.layernorm_fwd(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d)
+                lin_ln(b["ao"][j], Lw["out"], hin, hmid, Lw["ln2"], b["x2"][j], b["st2"][j], **ad)
+            # fc2's result feeds the NEXT layer's first LayerNorm (or the encoder's final one)
+            if i + 1 < ne:
+                jn = i + 1 if train else 0
+                nxt = None if fuse_ln_at(i + 1) else (self.enc[i + 1]["ln1"], b["x1"][jn], b["st1"][jn])
+            else:
+                nxt = (self.enc_ln, b["enc16"], b["enc_st"])
+
+            def fc2(**ad2):
+                nonlocal ln1_done, final_done
+                if nxt is None:
+                    self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, **ad2)
+                    return
+                lin_ln(b["gf"][j], Lw["fc2"], hmid, hout, *nxt, **ad2)
+                ln1_done, final_done = i + 1 < ne, i + 1 == ne
             if r:
                 if not fuse_ln:
                     self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
@@ -757,14 +789,15 @@ class MegWhisperEngine:
                 else:
                     self._gemm(A=b["gf"][j], am=rowmap(f), K=f, B=lo["fc2_A"], ldb=f, M=M, N=r, C16=b["u2"][j], c16m=rowmap(r),
                              flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 3)
-                self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
+                fc2(A2=b["u2"][j], lda2=r, K2=r, B2=lo["fc2_sB"])
             else:
                 self._lin(b["x2"][j], M, Lw["fc1"], C16=b["pre_f"][j] if train else None, G16=b["gf"][j], gelu=True)
-                self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout)
+                fc2()
         r = rank
         hlast = h[2 * dims.enc_layers] if train else h[0]
         b["h_last"] = hlast
-        ops.layernorm_fwd(hlast, *self.enc_ln, b["enc16"], *b["enc_st"], M, d)
+        if not final_done:
+            ops.layernorm_fwd(hlast, *self.enc_ln, b["enc16"], *b["enc_st"], M, d)
         self._mark("enc_fwd_end")
         return b["enc16"]
 
@@ -1136,7 +1169,8 @@ class MegWhisperEngine:
         # feed's few staging slots and is captured by address.
         import dataclasses
         key = (tuple(x32.shape), tuple(labels.shape), x32.xin.data_ptr() if packed else 0, cut, dataclasses.astuple(self.tc),
-               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs, self.no_ln_lora)
+               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs, self.no_ln_lora,
+               self.use_rowln)
         g = self._graphs.get(key)
         if g is None:
             warm = (tuple(x32.shape), tuple(labels.shape))

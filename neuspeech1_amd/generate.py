@@ -141,12 +141,15 @@ class Generator:
 
         # Row ranges of the batch as independent chains on separate streams: a decode step is a serial chain in
         # which the HBM-bound cross-attention (393 MB per layer at B = 128, ~5.5 TB/s) and the latency-bound small-M projections /
-        # LayerNorms (a few hundred CUs' worth of work at best) alternate, each leaving the other resource idle.  With the
-        # sequences cut into `nsplit` ranges that run the six layers on a stream each, one range streams its cross K/V while the
-        # others are in their projection chains.  Every kernel is row-independent (a row's results do not depend on which other
-        # rows share its launch, as long as the same kernel is dispatched), the ranges join before the final LayerNorm / LM head /
-        # selection.  NS_DECODE_SPLIT overrides (1 = one chain).
-        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or (2 if B >= 32 else 1)
+        # LayerNorms alternate, each leaving the other resource idle; with the sequences cut into `nsplit` ranges that run the
+        # six layers on a stream each, one range could stream its cross K/V while the others are in their projection chains.
+        # Every kernel is row-independent, the ranges join before the final LayerNorm / LM head / selection, ids are identical
+        # (tests/test_generate_gpu.py::test_split_decode_chains_give_the_same_ids).  MEASURED (round 5, B = 128, 64 new tokens,
+        # same box): greedy 105.9 k tokens/s with one chain, 85.6 k with two, 74.6 k with four; beam-5 82.3 / 75.5 / 66.0 k --
+        # a replayed hipGraph runs its branches one after the other on this stack (tools/probe/graph_branch_overlap.py), so the
+        # halves' small launches simply add up, and launched eagerly two chains are host-bound (55.5 k).  OFF by default;
+        # NS_DECODE_SPLIT=n turns it on.
+        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or 1
         nsplit = max(1, min(nsplit, B))
         cuts = [B * k // nsplit for k in range(nsplit + 1)]
         side = [torch.cuda.Stream(dev) for _ in range(nsplit - 1)] if dev.type == "cuda" else []

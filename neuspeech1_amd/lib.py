@@ -57,6 +57,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmLnDesc(C.Structure):
+    _fields_ = [("g", GemmDesc), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("ldx", C.c_int32),
+                ("x16", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p)]
+
+
 class Span(C.Structure):
     _fields_ = [("p", C.c_void_p), ("bytes", C.c_size_t)]
 
@@ -181,6 +186,8 @@ SIGNATURES = {
     "ns_last_error": (C.c_char_p, []),
     "ns_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ns_debug_set_ring": (None, [C.c_int]),
+    "ns_gemm_ln_supported": (C.c_int, [_i, _i, _i, _i]),
+    "ns_gemm_ln": (C.c_int, [C.POINTER(GemmLnDesc), _vp]),
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ns_layernorm_fwd_lora_supported": (C.c_int, [_i, _i, _i]),

@@ -46,13 +46,10 @@ _ZERO_MAP = RowMap(0, 0, 0)
 GEMM_PROFILE = None   # set to a list by bench.py to time every GEMM launch with HIP events
 
 
-def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
-         bias=None, C16=None, c16m=None, G16=None, g16m=None, P16=None, p16m=None, R32=None, H32=None, h32m=None,
-         pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0,
-         side_B=None, side_ldb=0, side_n=0, side_out=None, side_drop_p=0.0, side_drop_seed=0, k_alg=None, seed_dev=None):
-    """k_alg: the ALGORITHMIC reduction length where K carries padding (the first conv: 3 x ch against 3 x ch_pad);
-    only the bench's FLOP count reads it"""
-    d = GemmDesc()
+def _fill_gemm_desc(d, *, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=None, ldb2=0, a2_ngroup=0,
+                    bias=None, C16=None, c16m=None, G16=None, g16m=None, P16=None, p16m=None, R32=None, H32=None, h32m=None,
+                    pos=None, pos_rows=0, C32=None, ldc32=0, flags=0, splits=1, drop_p=0.0, drop_seed=0, alpha=0.0,
+                    side_B=None, side_ldb=0, side_n=0, side_out=None, side_drop_p=0.0, side_drop_seed=0, k_alg=None, seed_dev=None):
     d.side_B, d.side_ldb, d.side_n, d.side_out = ptr(side_B), side_ldb, side_n, ptr(side_out)
     d.side_drop_p, d.side_drop_seed = side_drop_p, side_drop_seed
     d.seed_dev = ptr(seed_dev)
@@ -71,10 +68,18 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     d.C32, d.ldc32 = ptr(C32), ldc32
     d.flags, d.splits = flags, splits
     d.drop_p, d.drop_seed, d.alpha = drop_p, drop_seed, alpha
+    return d
+
+
+def gemm(**kw):
+    """ns_gemm (keyword arguments = the descriptor's fields, see _fill_gemm_desc).  k_alg: the ALGORITHMIC reduction length where K
+    carries padding (the first conv: 3 x ch against 3 x ch_pad); only the bench's FLOP count reads it"""
+    d = _fill_gemm_desc(GemmDesc(), **kw)
     if GEMM_PROFILE is None:
         L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
         return
     # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
+    M, N, K, K2, flags = kw["M"], kw["N"], kw["K"], kw.get("K2", 0), kw.get("flags", 0)
     if flags & NS_GEMM_TN:
         kind = "tn"
     elif N <= 96 or (M <= 1024 and N <= 4096):
@@ -85,7 +90,28 @@ def gemm(*, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=None, K2=0, B2=No
     e0.record(torch.cuda.current_stream())
     L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
     e1.record(torch.cuda.current_stream())
-    GEMM_PROFILE.append((kind, 2.0 * M * N * ((k_alg or K) + K2 + (side_n if side_B is not None else 0)), e0, e1))   # side product: 2 M N side_n more
+    side = kw.get("side_n", 0) if kw.get("side_B") is not None else 0      # side product: 2 M N side_n more
+    GEMM_PROFILE.append((kind, 2.0 * M * N * ((kw.get("k_alg") or K) + K2 + side), e0, e1))
+
+
+def gemm_ln_supported(M: int, N: int, K: int, K2: int = 0) -> bool:
+    return bool(L.load().ns_gemm_ln_supported(M, N, K, K2))
+
+
+def gemm_ln(*, gamma, beta, x16, ldx, mean=None, rstd=None, eps=1e-5, **kw):
+    """ns_gemm_ln: the residual Linear described by **kw (as for gemm: N = 512, R32, H32) + the LayerNorm that reads H32"""
+    q = L.GemmLnDesc()
+    _fill_gemm_desc(q.g, **kw)
+    q.gamma, q.beta, q.eps, q.ldx = ptr(gamma), ptr(beta), eps, ldx
+    q.x16, q.mean, q.rstd = ptr(x16), ptr(mean), ptr(rstd)
+    if GEMM_PROFILE is None:
+        L.check(L.load().ns_gemm_ln(C.byref(q), _stream()), "ns_gemm_ln")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    L.check(L.load().ns_gemm_ln(C.byref(q), _stream()), "ns_gemm_ln")
+    e1.record(torch.cuda.current_stream())
+    GEMM_PROFILE.append(("rowln", 2.0 * kw["M"] * kw["N"] * (kw["K"] + kw.get("K2", 0)), e0, e1))
 
 
 def gemm_side_supported(M: int, N: int, K: int) -> bool:

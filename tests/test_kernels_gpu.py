@@ -1045,3 +1045,47 @@ def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
     close(ref["second_k2_16"][0], sec, 6e-3, 3e-3, "second product, K2 = 16")
     sec1 = A.float() @ B.float().T + u[:, :16].float() @ Bs[:, :16].float().T
     close(got["second_k2_16_one_group"][0], sec1, 6e-3, 3e-3, "second product through LDS, K2 = 16")
+
+
+@pytest.mark.parametrize("M,K,K2", [(96000, 512, 32), (96000, 2048, 32), (4500, 512, 0), (4500, 2048, 16), (1500 * 7, 1024, 32)])
+def test_gemm_ln_is_bitwise_the_two_launches(ops, dev, M, K, K2):
+    """ns_gemm_ln (csrc/ns_gemm_rowln.hip: residual Linear with N = 512 + the LayerNorm that reads its result, a workgroup owning
+    complete rows) against ns_gemm followed by ns_layernorm_fwd on the same operands: H32, x16, mean and rstd BITWISE equal
+    (same MFMA products in the same order, the same LayerNorm sums and shuffle tree), at the bench's row count, with a ragged last
+    row tile, with and without the LoRA second product (K2 = 32, and 16 = a zero-padded rank), against torch fp32 as well."""
+    N = 512
+    assert ops.gemm_ln_supported(M, N, K, K2)
+    A = rnd((M, K), dev, 1.0, seed=1)
+    W = rnd((N, K), dev, K ** -0.5, seed=2)
+    bias = rnd((N,), dev, 0.1, torch.float32, seed=3)
+    R = rnd((M, N), dev, 2.0, torch.float32, seed=4)
+    gamma = rnd((N,), dev, 1.0, torch.float32, seed=5) * 0.2 + 1.0
+    beta = rnd((N,), dev, 0.1, torch.float32, seed=6)
+    kw = dict(A=A, am=ops.rowmap(K), K=K, B=W, ldb=K, M=M, N=N, bias=bias, R32=R, h32m=ops.rowmap(N))
+    if K2:
+        u = rnd((M, 32), dev, 0.5, seed=7)
+        sB = rnd((N, 32), dev, 0.2, seed=8)
+        if K2 == 16:
+            u[:, 16:] = 0
+        kw.update(A2=u, am2=ops.rowmap(32), K2=K2, B2=sB, ldb2=32)
+    H0 = torch.empty(M, N, device=dev)
+    x0 = torch.empty(M, N, device=dev, dtype=torch.float16)
+    m0, r0 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.gemm(H32=H0, **kw)
+    ops.layernorm_fwd(H0, gamma, beta, x0, m0, r0, M, N)
+    H1 = torch.full((M, N), float("nan"), device=dev)
+    x1 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    m1, r1 = torch.full((M,), float("nan"), device=dev), torch.full((M,), float("nan"), device=dev)
+    ops.gemm_ln(H32=H1, gamma=gamma, beta=beta, x16=x1, ldx=N, mean=m1, rstd=r1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(H1, H0), f"H32 differs in {(H1 != H0).sum().item()} places, max {(H1 - H0).abs().max().item()}"
+    assert torch.equal(m1, m0) and torch.equal(r1, r0)
+    assert torch.equal(x1.view(torch.int16), x0.view(torch.int16))
+    # and against torch fp32 on a row slice (the two-launch path has its own tests; this guards the comparison itself)
+    sl = slice(M - 300, M)
+    y = A[sl].float() @ W.float().t() + bias
+    if K2:
+        y = y + u[sl, :K2].float() @ sB[:, :K2].float().t()
+    h = R[sl] + y.half().float()
+    close(H1[sl], h, 2e-2, 2e-3, "H32 vs torch")
+    close(x1[sl], F.layer_norm(h, (N,), gamma, beta, 1e-5), 2e-2, 1e-2, "x16 vs torch")
