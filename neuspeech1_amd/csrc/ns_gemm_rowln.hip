@@ -23,18 +23,18 @@
 // 4 l .. 4 l + 3 and 256 + 4 l .. + 3, the same sums and shuffle tree): H32, x16, mean and rstd are BITWISE what the two launches
 // produce (tests/test_kernels_gpu.py::test_gemm_ln_is_bitwise_the_two_launches).
 #include "ns_gemm_epi.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 64, BN = 512, BK = 32, NTH = 256;
 constexpr int A_ST = BM * 64;            // 4 KiB: one 32-deep step of the 64 A rows
-constexpr int NA = 4;
 constexpr int B_ST = BN * 64;            // 32 KiB: one 32-deep step of the 512 B rows
 constexpr int NB = 2;
 constexpr int A_OFF = NB * B_ST;
-constexpr int LDS_BYTES = NB * B_ST + NA * A_ST;     // 80 KiB: two workgroups per CU
 constexpr int LDH = BN * 2 + 16;         // epilogue: bytes per staged fp16 row
-static_assert(BM * LDH <= LDS_BYTES, "the staged fp16 tile reuses the rings");
+constexpr int lds_bytes(int na) { return NB * B_ST + na * A_ST; }      // NA = 4: 80 KiB, two workgroups per CU
+static_assert(BM * LDH <= lds_bytes(3), "the staged fp16 tile reuses the rings");
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -48,6 +48,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int sigma4(int x) { return (0x1320 >> (4 * x)) & 3; }   // (0, 2, 3, 1)
 
+template <int NA>
 __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ns_gemm_desc& p = q.g;
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
     }
   }
   const int nsteps = p.K / BK;
-  auto dma_a = [&](int t) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + A_OFF + (t & 3) * A_ST + wave * 1024), 16,
+  // (A stage of step t: t mod NA; the loop below is unrolled NA x 2 steps deep, so the index is a compile-time constant there)
+  auto dma_a = [&](int t, int slot) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + A_OFF + slot * A_ST + wave * 1024), 16,
                                              t < nsteps ? a_off : 0x80000000u, 2 * BK * t, 0, 0);
   };
   auto dma_b = [&](int t, int j) __attribute__((always_inline)) {
@@ -104,17 +106,21 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b2f[nt]) : "v"(bp) : "memory");
     }
   }
-  // ---- prologue: A(0), B(0) | A(1), A(2), B(1), A(3)   (1 + 8 | 1 + 1 + 8 + 1 pieces)
-  dma_a(0);
+  // ---- prologue, in the loop's own request order: A(0), B(0) | A(1) .. A(NA - 2), B(1), A(NA - 1)   (1 + 8 | NA - 2 + 8 + 1 pieces)
+  dma_a(0, 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) dma_b(0, j);
-  dma_a(1);
-  dma_a(2);
+#pragma unroll
+  for (int t = 1; t < NA - 1; ++t) dma_a(t, t);
 #pragma unroll
   for (int j = 0; j < 8; ++j) dma_b(1, j);
-  dma_a(3);
+  dma_a(NA - 1, NA - 1);
   if (p.K2 > 0) {
-    asm volatile("s_waitcnt vmcnt(20)"
+    if (NA == 4) asm volatile("s_waitcnt vmcnt(20)"
+                 : "+v"(a2f[0]), "+v"(a2f[1]), "+v"(a2f[2]), "+v"(a2f[3]), "+v"(b2f[0]), "+v"(b2f[1]), "+v"(b2f[2]), "+v"(b2f[3]),
+                   "+v"(b2f[4]), "+v"(b2f[5]), "+v"(b2f[6]), "+v"(b2f[7])
+                 :: "memory");
+    else asm volatile("s_waitcnt vmcnt(19)"
                  : "+v"(a2f[0]), "+v"(a2f[1]), "+v"(a2f[2]), "+v"(a2f[3]), "+v"(b2f[0]), "+v"(b2f[1]), "+v"(b2f[2]), "+v"(b2f[3]),
                    "+v"(b2f[4]), "+v"(b2f[5]), "+v"(b2f[6]), "+v"(b2f[7])
                  :: "memory");
@@ -132,8 +138,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
 
   const int fro = l15 * 64 + ((lg ^ sigma4((l15 >> 2) & 3)) << 4);
   half8 af[4], bf[2][8];
-  auto read_a = [&](int t, int mt) __attribute__((always_inline)) {
-    af[mt] = *(const half8*)(smem + A_OFF + (t & 3) * A_ST + mt * 1024 + fro);
+  auto read_a = [&](int slot, int mt) __attribute__((always_inline)) {
+    af[mt] = *(const half8*)(smem + A_OFF + slot * A_ST + mt * 1024 + fro);
   };
   auto read_b = [&](int t, int set, int nt) __attribute__((always_inline)) {
     bf[set][nt] = *(const half8*)(smem + (t & 1) * B_ST + (8 * wave + nt) * 1024 + fro);
@@ -141,30 +147,36 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
   auto mma = [&](int set, int mt, int nt) __attribute__((always_inline)) {
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[set][nt], af[mt], acc[mt][nt], 0, 0, 0);
   };
-  asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // A(0) and B(0) have landed
+  if (NA == 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // A(0) and B(0) have landed
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   RL_BARRIER();
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) read_b(0, 0, nt);
   read_a(0, 0);
   read_a(0, 1);
+  // (B(2) is requested by step 0's first half: stage 0 must have been read -- it has, just above, once lgkmcnt(0) has passed)
 
-  // One step = 32 MFMAs per wave around ONE barrier.  Before it: rows 0..31 of the wave tile, the step's last two A fragments.  Behind
-  // it (every wave has read A(t); this wave has read B(t)): rows 32..63, the fragments of step t + 1, the requests B(t + 2) -> the
-  // stage B(t) leaves and A(t + 4) -> the stage A(t) leaves.  The counted wait in front of the barrier lets only the newest piece,
-  // A(t + 3), stay in flight: B(t + 1) -- requested one step ago -- and A(t + 1), A(t + 2) have landed.
-  auto step = [&](int t, int set) __attribute__((always_inline)) {
+  // One step = 32 MFMAs per wave around ONE barrier.  Before it: rows 0..31 of the wave tile, the step's last two A fragments, and the
+  // requests B(t + 2) -> the stage B(t) left when its fragments were read in the previous step (wave-private: no barrier needed, and
+  // issued HERE, not behind the barrier, the pieces have a step and a half to arrive from L2: with one step the loop ran at the
+  // L2 round trip per step).  Behind it (every wave has read A(t)): rows 32..63, the fragments of step t + 1, the request A(t + NA)
+  // -> the stage A(t) leaves.  The counted wait in front of the barrier lets the nine newest pieces stay in flight -- B(t + 2) and
+  // A(t + NA - 1) -- so B(t + 1), requested a step and a half ago, and A(t + 1) have landed.
+  auto step = [&](int t, int set, int sa, int sa1) __attribute__((always_inline)) {      // sa = t mod NA, sa1 = (t + 1) mod NA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RL_SB();
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int mt = h >> 1, nb = (h & 1) * 4;
       mma(set, mt, nb + 0); mma(set, mt, nb + 1);
-      if (h < 2) read_a(t, 2 + h);
+      if (h < 2) read_a(sa, 2 + h);
+      dma_b(t + 2, 2 * h);
+      dma_b(t + 2, 2 * h + 1);
       mma(set, mt, nb + 2); mma(set, mt, nb + 3);
       RL_SB();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     RL_BARRIER();
     RL_SB();
 #pragma unroll
@@ -173,17 +185,18 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
       mma(set, mt, nb + 0); mma(set, mt, nb + 1);
       read_b(t + 1, set ^ 1, 2 * h);
       read_b(t + 1, set ^ 1, 2 * h + 1);
-      if (h >= 2) read_a(t + 1, h - 2);          // af[0..1] are dead from the first half on
-      dma_b(t + 2, 2 * h);
-      dma_b(t + 2, 2 * h + 1);
-      if (h == 3) dma_a(t + 4);
+      if (h >= 2) read_a(sa1, h - 2);            // af[0..1] are dead from the first half on
+      if (h == 3) dma_a(t + NA, sa);
       mma(set, mt, nb + 2); mma(set, mt, nb + 3);
       RL_SB();
     }
   };
-  for (int t = 0; t < nsteps; t += 2) {
-    step(t, 0);
-    step(t + 1, 1);
+  // unrolled over lcm(2, NA) steps so that the B set and the A stage of every step are compile-time constants
+  constexpr int UN = (NA % 2 == 0) ? NA : 2 * NA;
+  for (int t = 0; t < nsteps; t += UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (t + u < nsteps) step(t + u, u & 1, u % NA, (u + 1) % NA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (zero) pieces must not land on the staged tile
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -298,9 +311,16 @@ extern "C" int ns_gemm_ln(const ns_gemm_ln_desc* q, void* stream) {
                                           : (long long)(d->M - 1) * m.ld;
     NS_CHECK_ARG(2 * (last + d->K + 64) < 0x7FFF0000LL && 2LL * BN * d->bm.ld < 0x7FFF0000LL, "ns_gemm_ln: operand beyond 2 GiB");
   }
-  static ns_dev_once attr_once;      // kernel attribute, once per device (ns_common.h)
-  if (!ns_dyn_lds_once(attr_once, {(const void*)gemm_ln_kernel}, LDS_BYTES, "ns_gemm_ln")) return NS_ERR_HIP;
-  hipLaunchKernelGGL(gemm_ln_kernel, dim3((d->M + BM - 1) / BM), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *q);
+  static ns_dev_once attr4, attr3;   // kernel attributes, once per device (ns_common.h)
+  static const int na = [] { const char* e = getenv("NS_RL_NA"); return e && atoi(e) == 3 ? 3 : 4; }();     // A/B knob: A ring depth
+  const dim3 grid((d->M + BM - 1) / BM);
+  if (na == 4) {
+    if (!ns_dyn_lds_once(attr4, {(const void*)gemm_ln_kernel<4>}, lds_bytes(4), "ns_gemm_ln")) return NS_ERR_HIP;
+    hipLaunchKernelGGL(gemm_ln_kernel<4>, grid, dim3(NTH), lds_bytes(4), (hipStream_t)stream, *q);
+  } else {
+    if (!ns_dyn_lds_once(attr3, {(const void*)gemm_ln_kernel<3>}, lds_bytes(3), "ns_gemm_ln")) return NS_ERR_HIP;
+    hipLaunchKernelGGL(gemm_ln_kernel<3>, grid, dim3(NTH), lds_bytes(3), (hipStream_t)stream, *q);
+  }
   NS_CHECK_LAUNCH("ns_gemm_ln");
   return NS_OK;
 }
