@@ -9,13 +9,13 @@
 // each pair bound by HBM (A once, R32 in, H32 out, x16 out = 588 MB = 107 us at 5.5 TB/s for K = 512).  A workgroup that owns
 // COMPLETE rows normalises them before they leave: no second pass over H32, and A is read once instead of once per column tile.
 //
-// Shape: 64 x 512 tile per 4-wave workgroup (wave tile 64 x 128: the accumulator arithmetic of ns_gemm_p8's 128 x 64 wave tile
-// transposed), TWO workgroups per CU (80 KiB of LDS each), so one workgroup's HBM-bound epilogue runs under the other's main
-// loop without any persistent-kernel bookkeeping.  K advances in 32-deep steps:
-//   B (the weights: L2 resident) is WAVE-PRIVATE -- wave w only ever reads rows 128 w .. 128 w + 127 -- and moves by LDS-DMA through a
-//     2-stage ring (2 x 32 KiB) that needs no barrier: a stage is requested one step ahead by the wave that reads it;
-//   A (the activations: straight from HBM, long latency) is shared by the four waves and moves through a 4-stage ring of 4 KiB,
-//     requested three steps ahead, one s_barrier per step (in the middle of the step's 32 MFMAs, as tools/probe/w4_gemm.hip).
+// Shape: 128 x 512 tile per 8-wave workgroup (2 x 4 waves, wave tile 64 x 128: the accumulator arithmetic of ns_gemm_p8's 128 x 64
+// wave tile transposed), one workgroup per CU.  (A first version ran 64 x 512 tiles, two workgroups per CU, so that one workgroup's
+// HBM-bound epilogue would run under the other's main loop: 176-185 us for K = 512 and 364 us for K = 2048 against 165 / 282 us for the
+// two launches -- every 64 rows re-stream the whole of W through LDS-DMA, 57 B per cycle and CU, which IS the L2 -> LDS limit of a CU.)
+// K advances in 32-deep steps through two LDS-DMA rings: B (the weights: L2 resident) 3 stages of 32 KiB, requested two and a
+// half steps ahead; A (the activations: straight from HBM) 4 stages of 8 KiB, requested three and a half steps ahead; one
+// s_barrier per step, in the middle of the step's 32 MFMAs per wave (tools/probe/w4_gemm.hip's schedule).
 // 64-B LDS rows, 16-B chunk g of row r at g ^ sigma((r >> 2) & 3), sigma = (0, 2, 3, 1): conflict-free ds_read_b128 fragments.
 //
 // Arithmetic order = ns_gemm_p8's (second product first, then K ascending in 32-deep v_mfma_f32_16x16x32_f16 products, the B rows on
@@ -23,18 +23,18 @@
 // 4 l .. 4 l + 3 and 256 + 4 l .. + 3, the same sums and shuffle tree): H32, x16, mean and rstd are BITWISE what the two launches
 // produce (tests/test_kernels_gpu.py::test_gemm_ln_is_bitwise_the_two_launches).
 #include "ns_gemm_epi.h"
-#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 64, BN = 512, BK = 32, NTH = 256;
-constexpr int A_ST = BM * 64;            // 4 KiB: one 32-deep step of the 64 A rows
+constexpr int BM = 128, BN = 512, BK = 32, NTH = 512;
+constexpr int A_ST = BM * 64;            // 8 KiB: one 32-deep step of the 128 A rows
+constexpr int NA = 4;
 constexpr int B_ST = BN * 64;            // 32 KiB: one 32-deep step of the 512 B rows
-constexpr int NB = 2;
+constexpr int NB = 3;
 constexpr int A_OFF = NB * B_ST;
 constexpr int LDH = BN * 2 + 16;         // epilogue: bytes per staged fp16 row
-constexpr int lds_bytes(int na) { return NB * B_ST + na * A_ST; }      // NA = 4: 80 KiB, two workgroups per CU
-static_assert(BM * LDH <= lds_bytes(3), "the staged fp16 tile reuses the rings");
+constexpr int RING_BYTES = NB * B_ST + NA * A_ST;                         // 128 KiB
+constexpr int LDS_BYTES = BM * LDH > RING_BYTES ? BM * LDH : RING_BYTES;  // the staged fp16 tile (130 KiB) reuses the rings
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -48,16 +48,16 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int sigma4(int x) { return (0x1320 >> (4 * x)) & 3; }   // (0, 2, 3, 1)
 
-template <int NA>
-__global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q) {
+__global__ __launch_bounds__(NTH) void gemm_ln_kernel(const ns_gemm_ln_desc q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ns_gemm_desc& p = q.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * BM;
 
-  // acc[mt][nt]: row m0 + 16 mt + l15, columns 128 wave + 16 nt + 4 lg + e
+  // acc[mt][nt]: row m0 + 64 wm + 16 mt + l15, columns 128 wn + 16 nt + 4 lg + e
   f32x4 acc[4][8];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -66,26 +66,26 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x80000000u, 0x00020000);
-  // DMA sources (byte offsets; a piece = 16 rows x 64 B, lane-linear in LDS): wave w fills A piece w and B pieces 8 w .. 8 w + 7
-  uint32_t a_off, b_off[8];
+  // DMA sources (byte offsets; a piece = 16 rows x 64 B, lane-linear in LDS): wave w fills A piece w and B pieces 4 w .. 4 w + 3
+  uint32_t a_off, b_off[4];
   {
     const int g = (lane & 3) ^ sigma4((lane >> 4) & 3);       // row in piece = lane >> 2, so (row >> 2) & 3 = (lane >> 4) & 3
     const int arow = min(m0 + 16 * wave + (lane >> 2), p.M - 1);
     a_off = 2u * (uint32_t)(ns_rm_off64(p.am, arow) + g * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int brow = 128 * wave + 16 * j + (lane >> 2);
+    for (int j = 0; j < 4; ++j) {
+      const int brow = 64 * wave + 16 * j + (lane >> 2);
       b_off[j] = 2u * ((uint32_t)brow * (uint32_t)p.bm.ld + (uint32_t)g * 8u);
     }
   }
   const int nsteps = p.K / BK;
-  // (A stage of step t: t mod NA; the loop below is unrolled NA x 2 steps deep, so the index is a compile-time constant there)
+  // (ring slots are passed in: the loop below is unrolled over lcm(NA, NB) steps, so they are compile-time constants there)
   auto dma_a = [&](int t, int slot) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + A_OFF + slot * A_ST + wave * 1024), 16,
                                              t < nsteps ? a_off : 0x80000000u, 2 * BK * t, 0, 0);
   };
-  auto dma_b = [&](int t, int j) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)(smem + (t & 1) * B_ST + (8 * wave + j) * 1024), 16,
+  auto dma_b = [&](int t, int slot, int j) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)(smem + slot * B_ST + (4 * wave + j) * 1024), 16,
                                              t < nsteps ? b_off[j] : 0x80000000u, 2 * BK * t, 0, 0);
   };
 
@@ -96,31 +96,27 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
   if (p.K2 > 0) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int row = min(m0 + mt * 16 + l15, p.M - 1);
+      const int row = min(m0 + 64 * wm + mt * 16 + l15, p.M - 1);
       const half_t* ap = (const half_t*)p.A2 + ns_rm_off64(p.am2, row) + (k2ok ? 8 * lg : 0);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a2f[mt]) : "v"(ap) : "memory");
     }
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const half_t* bp = (const half_t*)p.B2 + (long long)(128 * wave + nt * 16 + l15) * p.ldb2 + (k2ok ? 8 * lg : 0);
+      const half_t* bp = (const half_t*)p.B2 + (long long)(128 * wn + nt * 16 + l15) * p.ldb2 + (k2ok ? 8 * lg : 0);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b2f[nt]) : "v"(bp) : "memory");
     }
   }
-  // ---- prologue, in the loop's own request order: A(0), B(0) | A(1) .. A(NA - 2), B(1), A(NA - 1)   (1 + 8 | NA - 2 + 8 + 1 pieces)
+  // ---- prologue, in the loop's own request order (step s requests B(s + 3), then A(s + 4)):
+  //      A(0) | B(0), A(1) | B(1), A(2) | B(2), A(3)        1 + 3 x 5 = 16 pieces
   dma_a(0, 0);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dma_b(0, j);
+  for (int s = 0; s < 3; ++s) {
 #pragma unroll
-  for (int t = 1; t < NA - 1; ++t) dma_a(t, t);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dma_b(1, j);
-  dma_a(NA - 1, NA - 1);
+    for (int j = 0; j < 4; ++j) dma_b(s, s, j);
+    dma_a(s + 1, s + 1);
+  }
   if (p.K2 > 0) {
-    if (NA == 4) asm volatile("s_waitcnt vmcnt(20)"
-                 : "+v"(a2f[0]), "+v"(a2f[1]), "+v"(a2f[2]), "+v"(a2f[3]), "+v"(b2f[0]), "+v"(b2f[1]), "+v"(b2f[2]), "+v"(b2f[3]),
-                   "+v"(b2f[4]), "+v"(b2f[5]), "+v"(b2f[6]), "+v"(b2f[7])
-                 :: "memory");
-    else asm volatile("s_waitcnt vmcnt(19)"
+    asm volatile("s_waitcnt vmcnt(16)"
                  : "+v"(a2f[0]), "+v"(a2f[1]), "+v"(a2f[2]), "+v"(a2f[3]), "+v"(b2f[0]), "+v"(b2f[1]), "+v"(b2f[2]), "+v"(b2f[3]),
                    "+v"(b2f[4]), "+v"(b2f[5]), "+v"(b2f[6]), "+v"(b2f[7])
                  :: "memory");
@@ -139,30 +135,27 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
   const int fro = l15 * 64 + ((lg ^ sigma4((l15 >> 2) & 3)) << 4);
   half8 af[4], bf[2][8];
   auto read_a = [&](int slot, int mt) __attribute__((always_inline)) {
-    af[mt] = *(const half8*)(smem + A_OFF + slot * A_ST + mt * 1024 + fro);
+    af[mt] = *(const half8*)(smem + A_OFF + slot * A_ST + (4 * wm + mt) * 1024 + fro);
   };
-  auto read_b = [&](int t, int set, int nt) __attribute__((always_inline)) {
-    bf[set][nt] = *(const half8*)(smem + (t & 1) * B_ST + (8 * wave + nt) * 1024 + fro);
+  auto read_b = [&](int slot, int set, int nt) __attribute__((always_inline)) {
+    bf[set][nt] = *(const half8*)(smem + slot * B_ST + (8 * wn + nt) * 1024 + fro);
   };
   auto mma = [&](int set, int mt, int nt) __attribute__((always_inline)) {
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[set][nt], af[mt], acc[mt][nt], 0, 0, 0);
   };
-  if (NA == 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // A(0) and B(0) have landed
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // A(0) and B(0) have landed (11 newer pieces may still travel)
   RL_BARRIER();
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) read_b(0, 0, nt);
   read_a(0, 0);
   read_a(0, 1);
-  // (B(2) is requested by step 0's first half: stage 0 must have been read -- it has, just above, once lgkmcnt(0) has passed)
 
-  // One step = 32 MFMAs per wave around ONE barrier.  Before it: rows 0..31 of the wave tile, the step's last two A fragments, and the
-  // requests B(t + 2) -> the stage B(t) left when its fragments were read in the previous step (wave-private: no barrier needed, and
-  // issued HERE, not behind the barrier, the pieces have a step and a half to arrive from L2: with one step the loop ran at the
-  // L2 round trip per step).  Behind it (every wave has read A(t)): rows 32..63, the fragments of step t + 1, the request A(t + NA)
-  // -> the stage A(t) leaves.  The counted wait in front of the barrier lets the nine newest pieces stay in flight -- B(t + 2) and
-  // A(t + NA - 1) -- so B(t + 1), requested a step and a half ago, and A(t + 1) have landed.
-  auto step = [&](int t, int set, int sa, int sa1) __attribute__((always_inline)) {      // sa = t mod NA, sa1 = (t + 1) mod NA
+  // One step = 32 MFMAs per wave around ONE barrier.  Before it: rows 0..31 of the wave tile and the step's last two A fragments.
+  // Behind it -- every wave has finished step t - 1, whose second half read the fragments of step t, so the stages of B(t) and A(t)
+  // are free --: rows 32..63, the fragments of step t + 1, the requests B(t + 3) -> B(t)'s stage and A(t + 4) -> A(t)'s stage.
+  // The counted wait in front of the barrier lets the six newest pieces travel on -- A(t + 2), B(t + 2), A(t + 3) -- so B(t + 1),
+  // requested a step and a half ago, and A(t + 1), requested two and a half steps ago, have landed.
+  auto step = [&](int t, int set, int sa, int sa1, int sb, int sb1) __attribute__((always_inline)) {   // slots of A(t), A(t+1), B(t), B(t+1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RL_SB();
 #pragma unroll
@@ -170,51 +163,49 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
       const int mt = h >> 1, nb = (h & 1) * 4;
       mma(set, mt, nb + 0); mma(set, mt, nb + 1);
       if (h < 2) read_a(sa, 2 + h);
-      dma_b(t + 2, 2 * h);
-      dma_b(t + 2, 2 * h + 1);
       mma(set, mt, nb + 2); mma(set, mt, nb + 3);
       RL_SB();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     RL_BARRIER();
     RL_SB();
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int mt = 2 + (h >> 1), nb = (h & 1) * 4;
       mma(set, mt, nb + 0); mma(set, mt, nb + 1);
-      read_b(t + 1, set ^ 1, 2 * h);
-      read_b(t + 1, set ^ 1, 2 * h + 1);
+      read_b(sb1, set ^ 1, 2 * h);
+      read_b(sb1, set ^ 1, 2 * h + 1);
       if (h >= 2) read_a(sa1, h - 2);            // af[0..1] are dead from the first half on
-      if (h == 3) dma_a(t + NA, sa);
+      dma_b(t + 3, sb, h);
+      if (h == 3) dma_a(t + 4, sa);
       mma(set, mt, nb + 2); mma(set, mt, nb + 3);
       RL_SB();
     }
   };
-  // unrolled over lcm(2, NA) steps so that the B set and the A stage of every step are compile-time constants
-  constexpr int UN = (NA % 2 == 0) ? NA : 2 * NA;
+  constexpr int UN = 12;       // lcm(2 fragment sets, NA = 4, NB = 3)
   for (int t = 0; t < nsteps; t += UN) {
 #pragma unroll
     for (int u = 0; u < UN; ++u)
-      if (t + u < nsteps) step(t + u, u & 1, u % NA, (u + 1) % NA);
+      if (t + u < nsteps) step(t + u, u & 1, u % NA, (u + 1) % NA, u % NB, (u + 1) % NB);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (zero) pieces must not land on the staged tile
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   RL_BARRIER();
 
-  // ---- epilogue, part 1: x alpha + bias, round to fp16 (the rounding point of the Linear's output), stage the 64 x 512 tile
+  // ---- epilogue, part 1: x alpha + bias, round to fp16 (the rounding point of the Linear's output), stage the 128 x 512 tile
   char* const hs = smem;
   const float alpha = p.alpha == 0.f ? 1.f : p.alpha;
   {
     float4 bz[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
-      bz[nt] = p.bias ? *(const float4*)(p.bias + 128 * wave + nt * 16 + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bz[nt] = p.bias ? *(const float4*)(p.bias + 128 * wn + nt * 16 + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        const int rl = mt * 16 + l15, cl = 128 * wave + nt * 16 + 4 * lg;
+        const int rl = 64 * wm + mt * 16 + l15, cl = 128 * wn + nt * 16 + 4 * lg;
         const f32x4 a = acc[mt][nt];
         const half4 h = {(half_t)(a[0] * alpha + bz[nt].x), (half_t)(a[1] * alpha + bz[nt].y), (half_t)(a[2] * alpha + bz[nt].z),
                          (half_t)(a[3] * alpha + bz[nt].w)};
@@ -245,7 +236,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
 #pragma unroll
   for (int i = 0; i < 2; ++i) { asm volatile("" : "+v"(gm[i])); asm volatile("" : "+v"(bt[i])); }
   half_t* const X16 = (half_t*)q.x16;
-  const float inv_d = 1.0f / 512.0f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int rl = 16 * wave + i, row = m0 + rl;
@@ -265,7 +255,6 @@ __global__ __launch_bounds__(NTH, 2) void gemm_ln_kernel(const ns_gemm_ln_desc q
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float c = h1[e] - mean; qq += c * c; }
     const float rstd = rsqrtf(ns_wave_sum(qq) / 512 + q.eps);
-    (void)inv_d;
     if (row < p.M) {
       float* const hp = p.H32 + ns_rm_off64(p.h32m, row);
       *(f32x4*)(hp + 4 * lane) = h0;
@@ -311,16 +300,9 @@ extern "C" int ns_gemm_ln(const ns_gemm_ln_desc* q, void* stream) {
                                           : (long long)(d->M - 1) * m.ld;
     NS_CHECK_ARG(2 * (last + d->K + 64) < 0x7FFF0000LL && 2LL * BN * d->bm.ld < 0x7FFF0000LL, "ns_gemm_ln: operand beyond 2 GiB");
   }
-  static ns_dev_once attr4, attr3;   // kernel attributes, once per device (ns_common.h)
-  static const int na = [] { const char* e = getenv("NS_RL_NA"); return e && atoi(e) == 3 ? 3 : 4; }();     // A/B knob: A ring depth
-  const dim3 grid((d->M + BM - 1) / BM);
-  if (na == 4) {
-    if (!ns_dyn_lds_once(attr4, {(const void*)gemm_ln_kernel<4>}, lds_bytes(4), "ns_gemm_ln")) return NS_ERR_HIP;
-    hipLaunchKernelGGL(gemm_ln_kernel<4>, grid, dim3(NTH), lds_bytes(4), (hipStream_t)stream, *q);
-  } else {
-    if (!ns_dyn_lds_once(attr3, {(const void*)gemm_ln_kernel<3>}, lds_bytes(3), "ns_gemm_ln")) return NS_ERR_HIP;
-    hipLaunchKernelGGL(gemm_ln_kernel<3>, grid, dim3(NTH), lds_bytes(3), (hipStream_t)stream, *q);
-  }
+  static ns_dev_once attr_once;      // kernel attribute, once per device (ns_common.h)
+  if (!ns_dyn_lds_once(attr_once, {(const void*)gemm_ln_kernel}, LDS_BYTES, "ns_gemm_ln")) return NS_ERR_HIP;
+  hipLaunchKernelGGL(gemm_ln_kernel, dim3((d->M + BM - 1) / BM), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *q);
   NS_CHECK_LAUNCH("ns_gemm_ln");
   return NS_OK;
 }
