@@ -209,9 +209,12 @@ class MegWhisperEngine:
         # Infinity Cache (the LayerNorm input was just written) and the one-workgroup-per-CU fused kernel takes 68 / 77 us against
         # 24 + 25 / 24 + 33 us (profiles/r4_a_bench_kernel_stats.csv).  NS_LN_LORA=1 turns it on.
         self.no_ln_lora = os.environ.get("NS_LN_LORA") != "1"
-        # residual Linear + the LayerNorm that reads its result in one launch (ns_gemm_ln: d = 512, bitwise the two launches' results);
-        # NS_ROWLN=0 keeps ns_gemm + ns_layernorm_fwd (A/B runs)
-        self.use_rowln = os.environ.get("NS_ROWLN", "1") != "0"
+        # residual Linear + the LayerNorm that reads its result in one launch (ns_gemm_ln: d = 512, bitwise the two launches' results).
+        # NS_ROWLN: 0 = ns_gemm + ns_layernorm_fwd everywhere, 1 = every residual Linear with d = 512, 2 (default) = only the K = 512
+        # out-projection.  Measured (round 5, same box, M = 96 000): K = 512 163.5 us against 166.6 us for the two launches; K = 2048 (fc2)
+        # 314.6 against 277.7 us -- the pair's second pass costs less than this kernel's slower main loop there; whole step 31.63 (mode 2) /
+        # 31.75-31.85 (mode 1) / 31.63-31.67 ms (mode 0): mode 2 takes six launches out of the step at the same time.
+        self.use_rowln = int(os.environ.get("NS_ROWLN", "2"))
         self._init_opt_state()
 
     # ------------------------------------------------------------------ trainables
@@ -714,7 +717,7 @@ class MegWhisperEngine:
 
         def lin_ln(x16, lin, R32, H32, ln, xout, st, A2=None, lda2=0, K2=0, B2=None):
             """residual Linear + the LayerNorm that reads its result: one launch (ns_gemm_ln, bitwise the pair's results) where built"""
-            if self.use_rowln and ops.gemm_ln_supported(M, lin.N, lin.K, K2):
+            if self.use_rowln and (self.use_rowln == 1 or lin.K == lin.N) and ops.gemm_ln_supported(M, lin.N, lin.K, K2):
                 ops.gemm_ln(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, A2=A2,
                             am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
                             R32=R32, H32=H32, h32m=rowmap(lin.N), gamma=ln[0], beta=ln[1], x16=xout, ldx=d, mean=st[0], rstd=st[1])
