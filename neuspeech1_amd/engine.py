@@ -194,6 +194,14 @@ class MegWhisperEngine:
             L["ln3"] = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
             self.dec.append(L)
         self.dec_ln = (g(dd + "layer_norm.weight"), g(dd + "layer_norm.bias"))
+        # The cross-attention K | V projections of ALL decoder layers read the same encoder states (HF:modeling_whisper.py:279-282 with
+        # key_value_states = encoder_hidden_states in every layer): in training they run as ONE GEMM with the layers' weights stacked
+        # (N = layers x 2d) and their input gradients as ONE GEMM over K = layers x 2d -- the encoder rows are streamed once instead of
+        # once per layer, and the fp32 encoder-state gradient is written once instead of being read, added to and rewritten per layer.
+        # NS_CKV_BATCH=0 keeps the per-layer launches (A/B runs); decoder adapters (--ft_full) always do.
+        self.ckv_batch = os.environ.get("NS_CKV_BATCH", "1") != "0" and not self.dec_lora and dims.dec_layers > 1
+        if self.ckv_batch:
+            self.ckv_all = _Lin(torch.cat([L["ckv"].w.float() for L in self.dec], 0), torch.cat([L["ckv"].bias for L in self.dec], 0))
         self._build_trainables(sd, lora_sd)
         self._bufs = {}
         # hipGraph replay of train_step (see there); NS_TRAIN_GRAPH=0 keeps every step eager
@@ -513,7 +521,14 @@ class MegWhisperEngine:
         b["enc16"] = h16(M, d)
         b["enc_st"] = (f32(M), f32(M))
         ndl = dims.dec_layers if train else 1
-        b["kv_c"] = [h16(M, 2 * d) for _ in range(ndl)]          # cross-attention K | V of the encoder rows, per decoder layer
+        # cross-attention K | V of the encoder rows, per decoder layer: (tensor, column offset) + row stride b["kv_ld"]
+        if train and self.ckv_batch:
+            b["kv_all"] = h16(M, ndl * 2 * d)
+            b["kv_c"] = [(b["kv_all"], i * 2 * d) for i in range(ndl)]
+            b["kv_ld"] = ndl * 2 * d
+        else:
+            b["kv_c"] = [(h16(M, 2 * d), 0) for _ in range(ndl)]
+            b["kv_ld"] = 2 * d
         if self.dec_lora:
             b["ud_ckv"] = [h16(M, 2 * r) for _ in range(ndl)]
         if train:
@@ -528,7 +543,11 @@ class MegWhisperEngine:
             nws = ops.attn_bwd_workspace_bytes(B, H, S, S) if os.environ.get("NS_ATTN_TWO_PASS") != "1" else 0
             b["attn_ws"] = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
             b["denc32"] = f32(M, d)
-            b["dkv_c"] = h16(M, 2 * d)
+            if self.ckv_batch:
+                b["dkv_all"] = h16(M, ndl * 2 * d)
+                b["dkv_c"] = [(b["dkv_all"], i * 2 * d) for i in range(ndl)]
+            else:
+                b["dkv_c"] = [(h16(M, 2 * d), 0)] * ndl
             if r:
                 b["du3"] = h16(M, 3 * r)
                 b["du"] = h16(M, r)
@@ -815,6 +834,10 @@ class MegWhisperEngine:
         hd = b["hd"]
         ops.embed_pos(dec_ids, self.E32, self.dec_pos, hd[0], ML, L, d)
         enc16 = b["enc16"]
+        kld = b["kv_ld"]
+        batched = "kv_all" in b
+        if batched:     # every layer's cross K | V in one GEMM over the encoder rows
+            self._lin(enc16, M, self.ckv_all, C16=b["kv_all"])
         for i, Lw in enumerate(self.dec):
             j = i if train else 0
             if train:
@@ -838,10 +861,11 @@ class MegWhisperEngine:
             lin("out", b["ao_s"][j], ML, 1, R32=h0, H32=h1)
             ops.layernorm_fwd(h1, *Lw["ln2"], b["xc"][j], *b["st_c"][j], ML, d)
             lin("cq", b["xc"][j], ML, 2, C16=b["q_c"][j])
-            lin("ckv", enc16, M, 3, C16=b["kv_c"][j])
-            kv = b["kv_c"][j]
-            ops.attn_fwd(Q=b["q_c"][j], K=kv, V=(kv, d), O=b["ao_c"][j], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
-                         ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][j])
+            kvt, ko = b["kv_c"][j]
+            if not batched:
+                lin("ckv", enc16, M, 3, C16=kvt)
+            ops.attn_fwd(Q=b["q_c"][j], K=(kvt, ko), V=(kvt, ko + d), O=b["ao_c"][j], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=kld,
+                         ldv=kld, ldo=d, causal=False, LSE=b["lse_c"][j])
             lin("cout", b["ao_c"][j], ML, 4, R32=h1, H32=h2)
             ops.layernorm_fwd(h2, *Lw["ln3"], b["xm"][j], *b["st_m"][j], ML, d)
             lin("fc1", b["xm"][j], ML, 5, C16=b["pre_fd"][j], G16=b["gfd"][j], gelu=True)
@@ -937,14 +961,15 @@ class MegWhisperEngine:
             ops.layernorm_bwd(b["ddx16"], False, h2, *b["st_m"][i], Lw["ln3"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
             # cross attention
             dgrad("cout", b["ddh16"], ML, b["ao_c"][i], 4, b["ddao"])
-            kv = b["kv_c"][i]
-            ops.attn_bwd(Q=b["q_c"][i], K=kv, V=(kv, d), O=b["ao_c"][i], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=2 * d,
-                         ldv=2 * d, ldo=d, causal=False, LSE=b["lse_c"][i], dO=b["ddao"], dQ=b["ddq_c"], dK=b["dkv_c"],
-                         dV=(b["dkv_c"], d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=2 * d, lddv=2 * d, workspace=b["attn_ws_c"])
+            (kvt, ko), (dkt, dko), kld = b["kv_c"][i], b["dkv_c"][i], b["kv_ld"]
+            ops.attn_bwd(Q=b["q_c"][i], K=(kvt, ko), V=(kvt, ko + d), O=b["ao_c"][i], B=B, H=H, Lq=L, Lk=S, ldq=d, ldk=kld,
+                         ldv=kld, ldo=d, causal=False, LSE=b["lse_c"][i], dO=b["ddao"], dQ=b["ddq_c"], dK=(dkt, dko),
+                         dV=(dkt, dko + d), Delta=b["ddelta"], lddo=d, lddq=d, lddk=kld, lddv=kld, workspace=b["attn_ws_c"])
             dgrad("cq", b["ddq_c"], ML, b["xc"][i], 2, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h1, *b["st_c"][i], Lw["ln2"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
             # encoder-state gradient accumulates in fp32 across the decoder layers
-            dgrad("ckv", b["dkv_c"], M, b["enc16"], 3, None, R32=None if first_enc else b["denc32"], H32=b["denc32"])
+            if "dkv_all" not in b:
+                dgrad("ckv", dkt, M, b["enc16"], 3, None, R32=None if first_enc else b["denc32"], H32=b["denc32"])
             first_enc = False
             # causal self attention
             dgrad("out", b["ddh16"], ML, b["ao_s"][i], 1, b["ddao"])
@@ -955,6 +980,8 @@ class MegWhisperEngine:
                          dV=(dq, 2 * d), Delta=b["ddelta"], lddo=d, lddq=3 * d, lddk=3 * d, lddv=3 * d)
             dgrad("qkv", dq, ML, b["xs"][i], 0, b["ddx16"])
             ops.layernorm_bwd(b["ddx16"], False, h0, *b["st_s"][i], Lw["ln1"][0], b["ddh32"], b["ddh32"], b["ddh16"], ML, d)
+        if "dkv_all" in b:      # the encoder-state gradient of all decoder layers' K | V projections: one GEMM over K = layers x 2d
+            self._dgrad(b["dkv_all"], M, self.ckv_all, None, H32=b["denc32"])
         # ---- encoder
         self._mark("enc_bwd_begin")
         h = b["h"]
