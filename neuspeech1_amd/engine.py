@@ -736,7 +736,10 @@ class MegWhisperEngine:
 
         def lin_ln(x16, lin, R32, H32, ln, xout, st, A2=None, lda2=0, K2=0, B2=None):
             """residual Linear + the LayerNorm that reads its result: one launch (ns_gemm_ln, bitwise the pair's results) where built"""
-            if self.use_rowln and (self.use_rowln == 1 or lin.K == lin.N) and ops.gemm_ln_supported(M, lin.N, lin.K, K2):
+            # (only where ns_gemm itself takes the phase-interleaved 256 x 256 kernel -- >= 192 tiles --, whose products ns_gemm_ln repeats
+            # bit for bit: below that the two launches run the 128 x 128 ring kernel and the fused form would differ in the last bit)
+            if self.use_rowln and (self.use_rowln == 1 or lin.K == lin.N) and ((M + 255) // 256) * ((lin.N + 255) // 256) >= 192 and \
+                    ops.gemm_ln_supported(M, lin.N, lin.K, K2):
                 ops.gemm_ln(A=x16, am=rowmap(lin.K), K=lin.K, B=lin.w, ldb=lin.K, M=M, N=lin.N, bias=lin.bias, A2=A2,
                             am2=rowmap(lda2) if A2 is not None else None, K2=K2, B2=B2, ldb2=K2 if B2 is not None else 0,
                             R32=R32, H32=H32, h32m=rowmap(lin.N), gamma=ln[0], beta=ln[1], x16=xout, ldx=d, mean=st[0], rstd=st[1])
