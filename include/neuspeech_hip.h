@@ -158,6 +158,10 @@ int ns_gemm_ln(const ns_gemm_ln_desc* d, void* stream);
 /* A/B knob for benchmarks: 1 (default) = automatic kernel choice, 0 = register-staged kernel only; 2..5 force one of
  * the wide NT kernels (see ns_gemm.hip), 6 = automatic without the small-M split-K kernel */
 void ns_debug_set_ring(int on);
+/* A/B knob: bit mask of the large-M launch classes that take the two-workgroups-per-CU kernel (csrc/ns_gemm_p4.hip; the NS_P4 environment
+ * variable sets the same mask): 1 plain, 2 GELU, 4 GELU + side product, 8 fp32 residual, 16 x gelu' / x P16, 32 the same with the adapter
+ * product under dropout, 64 plain with the adapter product under dropout.  Outputs are bit-identical whatever the mask. */
+void ns_debug_set_p4(int mask);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the fp32 residual stream (eps 1e-5, affine), one row = d

@@ -965,8 +965,10 @@ def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
     close(C, ref, 2e-3, 2e-3, "split-K NT")
 
 
-def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
-    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 700 tiles) against ns_gemm_p8 (one tile per
+@pytest.mark.parametrize("form", ["p8s", "p4"])
+def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev, form):
+    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 700 tiles) and ns_gemm_p4 (128 x 256 tiles, two
+    workgroups per CU: csrc/ns_gemm_p4.hip) against ns_gemm_p8 (one tile per
     workgroup) on ragged shapes with > 256 tiles, so that workgroups really carry the next tile's prologue through an epilogue:
     every epilogue kind, second product (ragged column groups, LoRA dropout), segmented row maps with an in-place residual, the
     GELU side product.  Same arithmetic in the same order: outputs must be bit-identical."""
@@ -1027,12 +1029,18 @@ def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev):
         out["gelu_side"] = (Cs, Gs, slab)
         return out
     try:
+        lib.load().ns_debug_set_p4(0)
         lib.load().ns_debug_set_ring(4)
         ref = run()
-        lib.load().ns_debug_set_ring(9)
+        if form == "p8s":
+            lib.load().ns_debug_set_ring(9)
+        else:
+            lib.load().ns_debug_set_ring(1)
+            lib.load().ns_debug_set_p4(127)
         got = run()
     finally:
         lib.load().ns_debug_set_ring(1)
+        lib.load().ns_debug_set_p4(-1)
     for k in ref:
         for a, b in zip(got[k], ref[k]):
             assert not torch.isnan(a.float()).any(), k
