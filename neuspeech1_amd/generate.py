@@ -145,10 +145,12 @@ class Generator:
         # six layers on a stream each, one range could stream its cross K/V while the others are in their projection chains.
         # Every kernel is row-independent, the ranges join before the final LayerNorm / LM head / selection, ids are identical
         # (tests/test_generate_gpu.py::test_split_decode_chains_give_the_same_ids).  MEASURED (round 5, B = 128, 64 new tokens,
-        # same box): greedy 105.9 k tokens/s with one chain, 85.6 k with two, 74.6 k with four; beam-5 82.3 / 75.5 / 66.0 k --
-        # a replayed hipGraph runs its branches one after the other on this stack (tools/probe/graph_branch_overlap.py), so the
-        # halves' small launches simply add up, and launched eagerly two chains are host-bound (55.5 k).  OFF by default;
-        # NS_DECODE_SPLIT=n turns it on.
+        # same box): greedy 105.9 k tokens/s with one chain, 85.6 k with two, 74.6 k with four; beam-5 82.3 / 75.5 / 66.0 k.
+        # The branches of a replayed hipGraph DO run concurrently on this stack (tools/probe/graph_branch_overlap.py: two chains
+        # of 65-us launches take 20.7 ms against 39.2 ms on one stream), but a decode step's launches are 4-9 us each: a range's
+        # chain costs as many launches whatever its row count, so two chains are twice the launches for the same dispatch rate,
+        # and the cross-attention stream, already at 5.5 TB/s, has nothing to gain from sharing the pipe.  Launched eagerly two
+        # chains are host-bound (55.5 k).  OFF by default; NS_DECODE_SPLIT=n turns it on.
         nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or 1
         nsplit = max(1, min(nsplit, B))
         cuts = [B * k // nsplit for k in range(nsplit + 1)]
