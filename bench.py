@@ -32,7 +32,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 # event-timed leg; in the rocprof stats its average launch = all ns_gemm_p8*_kernel rows together
 DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
 PMC_FILE = "profiles/r5_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
-DECODE_PMC_FILE = "profiles/r4_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
+DECODE_PMC_FILE = "profiles/r5_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
 LV2_GFLOP_PER_SAMPLE = 5630.0   # whisper-large-v2, 273-ch, fwd+bwd
 
 

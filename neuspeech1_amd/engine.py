@@ -618,7 +618,7 @@ class MegWhisperEngine:
                  C16=C16, c16m=rowmap(ldc or lin.N) if C16 is not None else None,
                  G16=G16, g16m=rowmap(lin.N) if G16 is not None else None,
                  R32=R32, H32=H32, h32m=rowmap(lin.N) if H32 is not None else None,
-                 flags=GELU_FWD if gelu else 0)
+                 flags=(GELU_FWD if C16 is not None else NS_GEMM_GELU) if gelu else 0)   # (no pre-activation output: inference, plain GELU)
 
     def _dgrad(self, dy16, M, lin: _Lin, out16, *, ldy=None, P16=None, A2=None, lda2=0, K2=0, B2=None,
                R32=None, H32=None, drop=False):
@@ -704,27 +704,28 @@ class MegWhisperEngine:
         c2 = self.conv_ops["conv2"]
         pb = lambda n: self.pview(f"model.encoder.{n}.bias")  # noqa: E731
         T2 = T // 2
+        gelu_f = GELU_FWD if train else NS_GEMM_GELU      # inference keeps no gelu' image (the C16 outputs below are None then)
         if self.frontend == "base":
             c0, c1 = self.conv_ops["conv1.0"], self.conv_ops["conv1.2"]
             # conv1.0 (k3,s1) + GELU  -> pre0 (plain), g0 (halo layout)
             self._gemm(A=xin, am=rowmap(Cp, T, (T + 2) * Cp), K=3 * Cp, B=c0["w"], ldb=3 * Cp, M=B * T, N=d, k_alg=3 * dims.ch,
                      bias=pb("conv1.0"), C16=b["pre0"] if train else None, c16m=rowmap(d), G16=(b["g0"], d),
-                     g16m=rowmap(d, T, (T + 2) * d), flags=GELU_FWD)
+                     g16m=rowmap(d, T, (T + 2) * d), flags=gelu_f)
             # conv1.2 (k3,s2) + the encoder's outer GELU
             self._gemm(A=b["g0"], am=rowmap(2 * d, T2, (T + 2) * d), K=3 * d, B=c1["w"], ldb=3 * d, M=B * T2, N=d,
                      bias=pb("conv1.2"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
-                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
+                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=gelu_f)
         else:
             # 'replace': one stride-2 conv over the packed signal + the encoder's outer GELU
             cr = self.conv_ops["conv1"]
             self._gemm(A=xin, am=rowmap(2 * Cp, T2, (T + 2) * Cp), K=3 * Cp, B=cr["w"], ldb=3 * Cp, M=B * T2, N=d,
                      bias=pb("conv1"), C16=b["pre1"] if train else None, c16m=rowmap(d), G16=(b["g1"], d),
-                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=GELU_FWD)
+                     g16m=rowmap(d, T2, (T2 + 2) * d), flags=gelu_f)
         # encoder.conv2 (k3,s2) + GELU + positions -> fp32 residual stream
         h = b["h"]
         self._gemm(A=b["g1"], am=rowmap(2 * d, S, (T2 + 2) * d), K=3 * d, B=c2["w"], ldb=3 * d, M=M, N=d,
                  bias=pb("conv2"), C16=b["pre2"] if train else None, c16m=rowmap(d), H32=h[0], h32m=rowmap(d), pos=self.enc_pos,
-                 pos_rows=S, flags=GELU_FWD)
+                 pos_rows=S, flags=gelu_f)
         dp = self._drop_p()
         rank = r
 
@@ -775,7 +776,7 @@ class MegWhisperEngine:
                 self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j])
             qkv = b["qkv"][j]
             ops.attn_fwd(Q=qkv, K=(qkv, d), V=(qkv, 2 * d), O=b["ao"][j], B=B, H=H, Lq=S, Lk=S, ldq=3 * d, ldk=3 * d,
-                         ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j])
+                         ldv=3 * d, ldo=d, causal=False, LSE=b["lse"][j] if train else None)
             ad = dict(A2=b["uo"][j], lda2=r, K2=r, B2=lo["out_sB"]) if r else {}
             if r:
                 self._gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
