@@ -74,6 +74,7 @@ class Generator:
         import os
         self.graph_min_steps = int(os.environ.get("NS_GRAPH_MIN_STEPS", 128)) if graph_min_steps is None else graph_min_steps
         self.split_graph_min_steps = int(os.environ.get("NS_SPLIT_GRAPH_MIN_STEPS", 16))
+        self.use_lists = os.environ.get("NS_LAUNCH_LISTS", "1") != "0"      # recorded launch lists for generations too short for graphs
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
@@ -157,26 +158,36 @@ class Generator:
         side = [torch.cuda.Stream(dev) for _ in range(nsplit - 1)] if dev.type == "cuda" else []
         self.last_split = nsplit
 
-        def layers(s0: int, s1: int, t: int, a, c1):
-            """the decoder layers for sequences [s0, s1) = rows [s0 * nb, s1 * nb); results in h[0] / h[1] by layer-count parity"""
-            r0, r1 = s0 * nb, s1 * nb
-            n = r1 - r0
-            hh = [h[0][r0:r1], h[1][r0:r1]]
-            x_, qkv_, qc_, ao_, gf_ = x16[r0:r1], qkv[r0:r1], qc[r0:r1], ao[r0:r1], gf[r0:r1]
-            st_ = (st[0][r0:r1], st[1][r0:r1])
+        # row-range views, made ONCE per generation: the loop below runs eagerly for short generations, and a dozen tensor slices per
+        # step (~1.5 us each on the host) were enough to make a 0.84-ms step host-bound (1.00 ms measured with the slices in the loop)
+        parts = []
+        for k in range(nsplit):
+            s0_, s1_ = cuts[k], cuts[k + 1]
+            r0_, r1_ = s0_ * nb, s1_ * nb
+            parts.append(dict(s0=s0_, s1=s1_, r0=r0_, n=r1_ - r0_, h={id(t_): t_[r0_:r1_] for t_ in h}, x=x16[r0_:r1_], qkv=qkv[r0_:r1_],
+                              qc=qc[r0_:r1_], ao=ao[r0_:r1_], gf=gf[r0_:r1_], st=(st[0][r0_:r1_], st[1][r0_:r1_]),
+                              anc={id(t_): t_[r0_:r1_] for t_ in anc}, kx=[kv_[s0_ * S:s1_ * S] for kv_ in kvx],
+                              vt=[v_[s0_:s1_] for v_ in vtx]))
+
+        def layers(pt: dict, t: int, a, c1):
+            """the decoder layers for the sequences of one row range; results in h[0] / h[1] by layer-count parity"""
+            s0, s1, r0, n = pt["s0"], pt["s1"], pt["r0"], pt["n"]
+            hh = [pt["h"][id(h[0])], pt["h"][id(h[1])]]
+            x_, qkv_, qc_, ao_, gf_, st_ = pt["x"], pt["qkv"], pt["qc"], pt["ao"], pt["gf"], pt["st"]
+            a_ = pt["anc"][id(a)]
             for li, Lw in enumerate(eng.dec):
                 ops.layernorm_fwd(hh[0], *Lw["ln1"], x_, *st_, n, d)
                 eng._lin(x_, n, Lw["qkv"], C16=qkv_)
                 # the kernel reads position t from this step's k | v rows and appends them to the cache itself
                 ops.attn_decode(Q=qkv_, K=kvc[li], V=(kvc[li], d), O=ao_, groups=n, nq=1, H=H, Lk=t + 1, Lk_max=max_len,
-                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a[r0:r1], anc_ld=max_len, kv_pos_stride=Bp,
+                                ldq=3 * d, ldk=2 * d, ldv=2 * d, ldo=d, anc=a_, anc_ld=max_len, kv_pos_stride=Bp,
                                 kv_len_dev=c1, Knew=(qkv_, d), Vnew=(qkv_, 2 * d), ldnew=3 * d, slot0=r0)
                 eng._lin(ao_, n, Lw["out"], R32=hh[0], H32=hh[1])
                 ops.layernorm_fwd(hh[1], *Lw["ln2"], x_, *st_, n, d)
                 eng._lin(x_, n, Lw["cq"], C16=qc_)
-                kx = kvx[li][s0 * S:s1 * S]
+                kx = pt["kx"][li]
                 if fewq:
-                    ops.attn_fewq(Q=qc_, K=kx, Vt=vtx[li][s0:s1], O=ao_, groups=s1 - s0, nq=nb, H=H, Lk=S, ldq=d, ldk=2 * d,
+                    ops.attn_fewq(Q=qc_, K=kx, Vt=pt["vt"][li], O=ao_, groups=s1 - s0, nq=nb, H=H, Lk=S, ldq=d, ldk=2 * d,
                                   ldvt=Sp, ldo=d)
                 elif nb > 1:
                     # beams of a sequence = the "queries" of one flash-attention problem over the sequence's encoder
@@ -203,14 +214,14 @@ class Generator:
             a = anc[0]
             ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t, pos0_dev=c0)
             if nsplit == 1:
-                layers(0, B, t, a, c1)
+                layers(parts[0], t, a, c1)
             else:
                 main = torch.cuda.current_stream()
                 for k, sd in enumerate(side):       # fork: every range starts behind the embedding
                     sd.wait_stream(main)
                     with torch.cuda.stream(sd):
-                        layers(cuts[k + 1], cuts[k + 2], t, a, c1)
-                layers(cuts[0], cuts[1], t, a, c1)
+                        layers(parts[k + 1], t, a, c1)
+                layers(parts[0], t, a, c1)
                 for sd in side:                     # join
                     main.wait_stream(sd)
             if len(eng.dec) % 2:
@@ -282,21 +293,38 @@ class Generator:
                     # two chains per step double the launches the host has to enqueue (~150 per step against ~0.6 ms of GPU time):
                     # with split chains the replayed graph is what keeps the loop GPU-bound, so even short generations capture
                     gms = self.graph_min_steps if nsplit == 1 else min(self.graph_min_steps, self.split_graph_min_steps)
-                    if graph_ok and max_len - cur >= gms:
+                    as_graph = graph_ok and max_len - cur >= gms
+                    # Shorter generations replay LAUNCH LISTS instead (ops.LaunchList: the same two (select, feed) pairs recorded
+                    # without being launched, exactly as a stream capture would; no hipGraph to instantiate): building ~80
+                    # descriptors through ctypes costs the host 0.8-1.0 ms per step against 0.84 ms of GPU time -- the driver's
+                    # 64-token eval leg ran host-bound on a slow host (100 k tokens/s against 108 k) -- and ~0.1 ms replayed.
+                    as_list = not as_graph and self.use_lists and nsplit == 1 and trace is None and max_len - cur >= 4
+                    if as_graph or as_list:
                         # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
                         ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
                         graphs = []
                         torch.cuda.synchronize()
+
+                        def feed():
+                            step(next_tok, cur, parent, ctr)
+                            ops.add_i32(ctr, 1)
+                            ops.add_i32((ctr, 1), 1)
                         for _ in range(2):
-                            gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                            # thread-local capture mode + the package's capture lock: other host threads (the data feed's
-                            # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
-                            with GPU_CAPTURE_LOCK:
-                                with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                            if as_list:
+                                gs, gt = ops.LaunchList(), ops.LaunchList()
+                                with ops.recording(gs):
                                     select(cur, ctr)
-                                with torch.cuda.graph(gt, capture_error_mode="thread_local"):
-                                    step(next_tok, cur, parent, ctr)
-                                    ctr.add_(1)
+                                with ops.recording(gt):
+                                    feed()
+                            else:
+                                gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                                # thread-local capture mode + the package's capture lock: other host threads (the data feed's
+                                # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
+                                with GPU_CAPTURE_LOCK:
+                                    with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                                        select(cur, ctr)
+                                    with torch.cuda.graph(gt, capture_error_mode="thread_local"):
+                                        feed()
                             graphs.append((gs, gt))
                 else:
                     graphs[(n_sel - 2) & 1][1].replay()
@@ -317,7 +345,7 @@ class Generator:
             tr_i = torch.empty(Bp, 2, device=dev, dtype=torch.int32) if trace is not None else None
 
             def select(c, ctr):
-                flags.zero_()
+                ops.zero_(flags)
                 if trace is not None:       # this step's two best processed scores per row, before the ids move on
                     ops.logits_select(ids=seqs[0], cur_len=c, log_softmax=False, cur_len_dev=ctr, k=2, group_rows=1,
                                       cand_vals=tr_v, cand_idx=tr_i, **proc)
@@ -356,7 +384,7 @@ class Generator:
                 else:
                     ops.logits_process(ids=seqs[0], cur_len=c, log_softmax=True, beam_scores=run_scores[0], cur_len_dev=ctr, **proc)
                     ops.topk_groups(scores, B, nb * V, 2 * nb, top_v, top_i)
-                flags.zero_()
+                ops.zero_(flags)
                 ops.beam_update(top_vals=top_v, top_idx=top_i, run_seqs_in=seqs[0], run_seqs_out=seqs[1],
                                 run_scores_out=run_scores[1], fin_seqs_in=fin_seqs[0], fin_seqs_out=fin_seqs[1],
                                 fin_scores_in=fin_scores[0], fin_scores_out=fin_scores[1], fin_done_in=fin_done[0],

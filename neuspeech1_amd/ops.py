@@ -27,6 +27,55 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- launch lists: a host-side stand-in for a hipGraph where capturing one does not pay (generate.py: short generations).
+# While a list is being RECORDED on this thread, entry points are not launched but appended -- function, marshalled arguments -- exactly
+# as a stream capture records instead of executing; replay() then issues them on the current stream at ~1 us of host time per launch,
+# where building a descriptor through ctypes costs ~10 us (40 field stores, a dozen data_ptr() calls): a decode step of ~80 launches is
+# 0.8-1.0 ms of host work built afresh against 0.84 ms of GPU time, i.e. host-bound on a slow host, and 0.1 ms replayed.
+import threading as _threading
+
+_tls = _threading.local()
+
+
+class LaunchList:
+    __slots__ = ("calls",)
+
+    def __init__(self):
+        self.calls = []
+
+    def replay(self):
+        st = _stream()
+        for fn, name, args in self.calls:
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, name)
+
+
+class recording:
+    """with ops.recording(launch_list): ... -- this thread's entry-point calls are recorded into the list, not launched"""
+
+    def __init__(self, lst: LaunchList):
+        self.lst = lst
+
+    def __enter__(self):
+        assert getattr(_tls, "rec", None) is None, "nested ops.recording"
+        _tls.rec = self.lst
+        return self.lst
+
+    def __exit__(self, *exc):
+        _tls.rec = None
+        return False
+
+
+def _call(name: str, *args):
+    fn = getattr(L.load(), name)
+    rec = getattr(_tls, "rec", None)
+    if rec is not None:
+        rec.calls.append((fn, name, args))
+        return
+    L.check(fn(*args, _stream()), name)
+
+
 def ptr(t, off: int = 0) -> int:
     """Device address of tensor element `off` (0 for None)."""
     if t is None:
@@ -76,7 +125,7 @@ def gemm(**kw):
     carries padding (the first conv: 3 x ch against 3 x ch_pad); only the bench's FLOP count reads it"""
     d = _fill_gemm_desc(GemmDesc(), **kw)
     if GEMM_PROFILE is None:
-        L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
+        _call("ns_gemm", C.byref(d))
         return
     # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
     M, N, K, K2, flags = kw["M"], kw["N"], kw["K"], kw.get("K2", 0), kw.get("flags", 0)
@@ -88,7 +137,7 @@ def gemm(**kw):
         kind = "nt256" if (N >= 256 and (M >= 2048 or (M >= 512 and N >= 8192)) and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
-    L.check(L.load().ns_gemm(C.byref(d), _stream()), "ns_gemm")
+    _call("ns_gemm", C.byref(d))
     e1.record(torch.cuda.current_stream())
     side = kw.get("side_n", 0) if kw.get("side_B") is not None else 0      # side product: 2 M N side_n more
     GEMM_PROFILE.append((kind, 2.0 * M * N * ((kw.get("k_alg") or K) + K2 + side), e0, e1))
@@ -105,11 +154,11 @@ def gemm_ln(*, gamma, beta, x16, ldx, mean=None, rstd=None, eps=1e-5, **kw):
     q.gamma, q.beta, q.eps, q.ldx = ptr(gamma), ptr(beta), eps, ldx
     q.x16, q.mean, q.rstd = ptr(x16), ptr(mean), ptr(rstd)
     if GEMM_PROFILE is None:
-        L.check(L.load().ns_gemm_ln(C.byref(q), _stream()), "ns_gemm_ln")
+        _call("ns_gemm_ln", C.byref(q))
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
-    L.check(L.load().ns_gemm_ln(C.byref(q), _stream()), "ns_gemm_ln")
+    _call("ns_gemm_ln", C.byref(q))
     e1.record(torch.cuda.current_stream())
     GEMM_PROFILE.append(("rowln", 2.0 * kw["M"] * kw["N"] * (kw["K"] + kw.get("K2", 0)), e0, e1))
 
@@ -119,12 +168,12 @@ def gemm_side_supported(M: int, N: int, K: int) -> bool:
 
 
 def gemm_side_reduce(slabs, tiles, M, alpha, u16, ldu):
-    L.check(L.load().ns_gemm_side_reduce(ptr(slabs), tiles, M, alpha, ptr(u16), ldu, _stream()), "ns_gemm_side_reduce")
+    _call("ns_gemm_side_reduce", ptr(slabs), tiles, M, alpha, ptr(u16), ldu)
 
 
 def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5):
-    L.check(L.load().ns_layernorm_fwd(ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean), ptr(rstd),
-                                      rows, d, eps, _stream()), "ns_layernorm_fwd")
+    _call("ns_layernorm_fwd", ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean), ptr(rstd),
+                                      rows, d, eps)
 
 
 def layernorm_fwd_lora_supported(rows, d, n_out):
@@ -134,37 +183,34 @@ def layernorm_fwd_lora_supported(rows, d, n_out):
 def layernorm_fwd_lora(x32, gamma, beta, y16, mean, rstd, rows, d, A16, lda, n_out, u16, ldu, alpha=1.0, drop_p=0.0, drop_seed=0,
                        seed_dev=None, eps=1e-5):
     """y16 = LN(x32) and u16 = round16(alpha * drop(y16) A16^T) in one pass (ns_layernorm_fwd_lora)"""
-    L.check(L.load().ns_layernorm_fwd_lora(ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(mean), ptr(rstd), rows, d, eps, ptr(A16), lda,
-                                           n_out, ptr(u16), ldu, alpha, drop_p, int(drop_seed) & 0xFFFFFFFF, ptr(seed_dev), _stream()),
-            "ns_layernorm_fwd_lora")
+    _call("ns_layernorm_fwd_lora", ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(mean), ptr(rstd), rows, d, eps, ptr(A16), lda,
+                                           n_out, ptr(u16), ldu, alpha, drop_p, int(drop_seed) & 0xFFFFFFFF, ptr(seed_dev))
 
 
 def layernorm_bwd(dy, dy_is_f32, x32, mean, rstd, gamma, dres, dx32, dx16, rows, d):
-    L.check(L.load().ns_layernorm_bwd(ptr(dy), int(dy_is_f32), ptr(x32), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
-                                      ptr(dx32), ptr(dx16), rows, d, _stream()), "ns_layernorm_bwd")
+    _call("ns_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x32), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
+                                      ptr(dx32), ptr(dx16), rows, d)
 
 
 def signal_pack(x32, out16, B, ch, T, Cp):
-    L.check(L.load().ns_signal_pack(ptr(x32), ptr(out16), B, ch, T, Cp, _stream()), "ns_signal_pack")
+    _call("ns_signal_pack", ptr(x32), ptr(out16), B, ch, T, Cp)
 
 
 def feed_pack(items_dev, B, ch, T, Cp, out16, x32=None):
     """items_dev: device uint8/int64 tensor holding B ns_feed_item records (32 bytes each)"""
-    L.check(L.load().ns_feed_pack(ptr(items_dev), B, ch, T, Cp, ptr(out16), ptr(x32), _stream()), "ns_feed_pack")
+    _call("ns_feed_pack", ptr(items_dev), B, ch, T, Cp, ptr(out16), ptr(x32))
 
 
 def embed_pos(ids, E32, P32, h32, rows, Lseq, d, pos0=0, pos0_dev=None):
-    L.check(L.load().ns_embed_pos(ptr(ids), ptr(E32), ptr(P32), ptr(h32), rows, Lseq, d, pos0, ptr(pos0_dev),
-                                  _stream()), "ns_embed_pos")
+    _call("ns_embed_pos", ptr(ids), ptr(E32), ptr(P32), ptr(h32), rows, Lseq, d, pos0, ptr(pos0_dev))
 
 
 def dgelu_mul(a16, pre16, out16, out_map, rows, cols, pre_is_grad=False):
-    L.check(L.load().ns_dgelu_mul(ptr(a16), ptr(pre16), ptr(out16), C.byref(out_map), rows, cols, int(pre_is_grad), _stream()),
-            "ns_dgelu_mul")
+    _call("ns_dgelu_mul", ptr(a16), ptr(pre16), ptr(out16), C.byref(out_map), rows, cols, int(pre_is_grad))
 
 
 def colsum(a16, out32, rows, cols, ld, alpha=1.0):
-    L.check(L.load().ns_colsum(ptr(a16), ptr(out32), rows, cols, ld, alpha, _stream()), "ns_colsum")
+    _call("ns_colsum", ptr(a16), ptr(out32), rows, cols, ld, alpha)
 
 
 def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, dO=None, dQ=None, dK=None, dV=None,
@@ -184,7 +230,7 @@ def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, d
 
 def attn_fwd(**kw):
     d = _attn_desc(**kw)
-    L.check(L.load().ns_attn_fwd(C.byref(d), _stream()), "ns_attn_fwd")
+    _call("ns_attn_fwd", C.byref(d))
 
 
 def attn_bwd_workspace_bytes(B, H, Lq, Lk, causal=False) -> int:
@@ -193,28 +239,25 @@ def attn_bwd_workspace_bytes(B, H, Lq, Lk, causal=False) -> int:
 
 def attn_bwd(**kw):
     d = _attn_desc(**kw)
-    L.check(L.load().ns_attn_bwd(C.byref(d), _stream()), "ns_attn_bwd")
+    _call("ns_attn_bwd", C.byref(d))
 
 
 def cross_entropy(logits16, labels, rows, V, ldv, row_loss, dlogits16, nvalid_dev, loss_scale_dev, loss_dev):
-    L.check(L.load().ns_cross_entropy(ptr(logits16), ptr(labels), rows, V, ldv, ptr(row_loss), ptr(dlogits16),
-                                      ptr(nvalid_dev), ptr(loss_scale_dev), ptr(loss_dev), _stream()),
-            "ns_cross_entropy")
+    _call("ns_cross_entropy", ptr(logits16), ptr(labels), rows, V, ldv, ptr(row_loss), ptr(dlogits16),
+                                      ptr(nvalid_dev), ptr(loss_scale_dev), ptr(loss_dev))
 
 
 def argmax_rows(logits16, rows, V, ldv, out):
-    L.check(L.load().ns_argmax_rows(ptr(logits16), rows, V, ldv, ptr(out), _stream()), "ns_argmax_rows")
+    _call("ns_argmax_rows", ptr(logits16), rows, V, ldv, ptr(out))
 
 
 def grad_norm(g32, n, workspace, norm2_dev, found_inf_dev):
-    L.check(L.load().ns_grad_norm(ptr(g32), n, ptr(workspace), ptr(norm2_dev), ptr(found_inf_dev), _stream()),
-            "ns_grad_norm")
+    _call("ns_grad_norm", ptr(g32), n, ptr(workspace), ptr(norm2_dev), ptr(found_inf_dev))
 
 
 def adamw_step(p, g, m, v, n, cfg: AdamWCfg, step_dev, norm2_dev, found_inf_dev, loss_scale_dev, growth_tracker_dev):
-    L.check(L.load().ns_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), n, C.byref(cfg), ptr(step_dev), ptr(norm2_dev),
-                                   ptr(found_inf_dev), ptr(loss_scale_dev), ptr(growth_tracker_dev), _stream()),
-            "ns_adamw_step")
+    _call("ns_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), n, C.byref(cfg), ptr(step_dev), ptr(norm2_dev),
+                                   ptr(found_inf_dev), ptr(loss_scale_dev), ptr(growth_tracker_dev))
 
 
 def zero_(*tensors):
@@ -226,7 +269,7 @@ def zero_(*tensors):
         for j, t in enumerate(chunk):
             assert t.is_contiguous()
             arr[j] = L.Span(t.data_ptr(), t.numel() * t.element_size())
-        L.check(L.load().ns_zero_spans(arr, len(chunk), _stream()), "ns_zero_spans")
+        _call("ns_zero_spans", arr, len(chunk))
 
 
 def zeros(*shape, device, dtype):
@@ -237,7 +280,7 @@ def zeros(*shape, device, dtype):
 
 
 def add_i32(counter_dev, v=1):
-    L.check(L.load().ns_add_i32(ptr(counter_dev), int(v), _stream()), "ns_add_i32")
+    _call("ns_add_i32", ptr(counter_dev), int(v))
 
 
 def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
@@ -252,7 +295,7 @@ def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:
 
 
 def cast_jobs(table: torch.Tensor, njobs: int):
-    L.check(L.load().ns_cast_jobs(ptr(table), njobs, _stream()), "ns_cast_jobs")
+    _call("ns_cast_jobs", ptr(table), njobs)
 
 
 # ----------------------------------------------------------------------------- decode loop
@@ -265,18 +308,18 @@ def attn_decode(*, Q, K, V, O, groups, nq, H, Lk, Lk_max, ldq, ldk, ldv, ldo, an
     d.ldq, d.ldk, d.ldv, d.ldo, d.anc_ld = ldq, ldk, ldv, ldo, anc_ld
     d.kv_group_stride, d.kv_pos_stride = kv_group_stride, kv_pos_stride
     d.Knew, d.Vnew, d.ldnew, d.slot0 = ptr(Knew), ptr(Vnew), ldnew, slot0
-    L.check(L.load().ns_attn_decode(C.byref(d), _stream()), "ns_attn_decode")
+    _call("ns_attn_decode", C.byref(d))
 
 
 def attn_fewq(*, Q, K, Vt, O, groups, nq, H, Lk, ldq, ldk, ldvt, ldo):
     d = L.AttnFewqDesc()
     d.Q, d.K, d.Vt, d.O = ptr(Q), ptr(K), ptr(Vt), ptr(O)
     d.groups, d.nq, d.H, d.Lk, d.ldq, d.ldk, d.ldvt, d.ldo = groups, nq, H, Lk, ldq, ldk, ldvt, ldo
-    L.check(L.load().ns_attn_fewq(C.byref(d), _stream()), "ns_attn_fewq")
+    _call("ns_attn_fewq", C.byref(d))
 
 
 def vt_pack(v16, ldv, vt16, groups, H, Lk, ldvt):
-    L.check(L.load().ns_vt_pack(ptr(v16), ldv, ptr(vt16), groups, H, Lk, ldvt, _stream()), "ns_vt_pack")
+    _call("ns_vt_pack", ptr(v16), ldv, ptr(vt16), groups, H, Lk, ldvt)
 
 
 def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, begin_index, log_softmax, beam_scores=None,
@@ -291,7 +334,7 @@ def logits_process(*, logits16, scores32, ids, rows, V, ldv, ids_ld, cur_len, be
     d.n_suppress, d.n_begin_suppress, d.no_repeat_ngram, d.log_softmax = n_suppress, n_begin_suppress, no_repeat_ngram, int(log_softmax)
     d.repetition_penalty = repetition_penalty
     d.bias1, d.seq_tok, d.seq_off, d.seq_bias, d.n_seq = ptr(bias1), ptr(seq_tok), ptr(seq_off), ptr(seq_bias), n_seq
-    L.check(L.load().ns_logits_process(C.byref(d), _stream()), "ns_logits_process")
+    _call("ns_logits_process", C.byref(d))
 
 
 SELECT_MAX_LDV = 26 * 256 * 8
@@ -309,11 +352,11 @@ def logits_select(*, logits16, ids, rows, V, ldv, ids_ld, cur_len, begin_index, 
     d.rows, d.V, d.ldv, d.ids_ld, d.cur_len, d.begin_index = rows, V, ldv, ids_ld, cur_len, begin_index
     d.n_suppress, d.n_begin_suppress, d.no_repeat_ngram, d.log_softmax = n_suppress, n_begin_suppress, no_repeat_ngram, int(log_softmax)
     d.repetition_penalty = repetition_penalty
-    L.check(L.load().ns_logits_select(C.byref(d), k, group_rows, ptr(cand_vals), ptr(cand_idx), _stream()), "ns_logits_select")
+    _call("ns_logits_select", C.byref(d), k, group_rows, ptr(cand_vals), ptr(cand_idx))
 
 
 def topk_merge(cand_vals, cand_idx, groups, ncand, k, vals, idx):
-    L.check(L.load().ns_topk_merge(ptr(cand_vals), ptr(cand_idx), groups, ncand, k, ptr(vals), ptr(idx), _stream()), "ns_topk_merge")
+    _call("ns_topk_merge", ptr(cand_vals), ptr(cand_idx), groups, ncand, k, ptr(vals), ptr(idx))
 
 
 _topk_ws = {}
@@ -325,30 +368,28 @@ def topk_groups(x32, groups, n, k, vals, idx):
     if ws is None:
         ws = torch.empty(L.load().ns_topk_workspace_bytes(groups, n, k), device=x32.device, dtype=torch.uint8)
         _topk_ws[key] = ws
-    L.check(L.load().ns_topk_groups(ptr(x32), groups, n, k, ptr(vals), ptr(idx), ptr(ws), _stream()), "ns_topk_groups")
+    _call("ns_topk_groups", ptr(x32), groups, n, k, ptr(vals), ptr(idx), ptr(ws))
 
 
 def beam_update(**kw):
     d = L.BeamDesc()
     for k, v in kw.items():
         setattr(d, k, ptr(v) if isinstance(v, (torch.Tensor, tuple)) or v is None else v)
-    L.check(L.load().ns_beam_update(C.byref(d), _stream()), "ns_beam_update")
+    _call("ns_beam_update", C.byref(d))
 
 
 def anc_update(anc_in, anc_out, parent, rows, ld, cur, cur_dev=None):
-    L.check(L.load().ns_anc_update(ptr(anc_in), ptr(anc_out), ptr(parent), rows, ld, cur, ptr(cur_dev), _stream()),
-            "ns_anc_update")
+    _call("ns_anc_update", ptr(anc_in), ptr(anc_out), ptr(parent), rows, ld, cur, ptr(cur_dev))
 
 
 def greedy_update(scores, rows, V, seqs, ld, cur, eos, pad, done, any_open, next_tok, cur_dev=None, best_idx=None):
-    L.check(L.load().ns_greedy_update(ptr(scores), rows, V, ptr(seqs), ld, cur, ptr(cur_dev), eos, pad, ptr(done), ptr(any_open),
-                                      ptr(next_tok), ptr(best_idx), _stream()), "ns_greedy_update")
+    _call("ns_greedy_update", ptr(scores), rows, V, ptr(seqs), ld, cur, ptr(cur_dev), eos, pad, ptr(done), ptr(any_open),
+                                      ptr(next_tok), ptr(best_idx))
 
 
 # ----------------------------------------------------------------------------- AdaLoRA
 def adalora_fold_grads(dBf, B, E, dB, dE, N, r, s):
-    L.check(L.load().ns_adalora_fold_grads(ptr(dBf), ptr(B), ptr(E), ptr(dB), ptr(dE), N, r, s, _stream()),
-            "ns_adalora_fold_grads")
+    _call("ns_adalora_fold_grads", ptr(dBf), ptr(B), ptr(E), ptr(dB), ptr(dE), N, r, s)
 
 
 def make_fold_jobs(jobs, device):
@@ -360,7 +401,7 @@ def make_fold_jobs(jobs, device):
 
 
 def adalora_fold_jobs(table, njobs):
-    L.check(L.load().ns_adalora_fold_jobs(ptr(table), njobs, _stream()), "ns_adalora_fold_jobs")
+    _call("ns_adalora_fold_jobs", ptr(table), njobs)
 
 
 def make_orth_jobs(jobs, device):
@@ -383,8 +424,7 @@ def orth_reg(table, njobs, weight_over_num, loss_scale_dev, reg_out_dev):
             _retired_ws.append(ws)      # a captured training step (hipGraph) may still hold its address
         ws = torch.empty(need, device=reg_out_dev.device, dtype=torch.uint8)
         _orth_ws[reg_out_dev.device] = ws
-    L.check(L.load().ns_orth_reg(ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), ptr(ws), ws.numel(),
-                                 _stream()), "ns_orth_reg")
+    _call("ns_orth_reg", ptr(table), njobs, weight_over_num, ptr(loss_scale_dev), ptr(reg_out_dev), ptr(ws), ws.numel())
 
 
 # ----------------------------------------------------------------------------- LoRA backward (du + dB in one pass over dy)
@@ -415,4 +455,4 @@ def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du
     d.M, d.N, d.r, d.G = M, N, r, G
     d.ldy, d.ldu, d.lddu, d.lddb = ldy, ldu, lddu, lddb
     d.alpha_du, d.splits = alpha_du, splits
-    L.check(L.load().ns_lora_bwd_dudb(C.byref(d), _stream()), "ns_lora_bwd_dudb")
+    _call("ns_lora_bwd_dudb", C.byref(d))
