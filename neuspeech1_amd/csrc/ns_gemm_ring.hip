@@ -13,7 +13,12 @@
 
 namespace {
 
-constexpr int BN = 128, BKS = 32, NST = 4, NTH = 256;     // BM = 128 or 64 (template): 64-row tiles when 128-row tiles leave most CUs idle
+constexpr int BN = 128, BKS = 32, NTH = 256;     // BM = 128 or 64 (template): 64-row tiles when 128-row tiles leave most CUs idle
+// ring depth: 4 slices, one barrier per slice (the dropout variants, whose mask sits between two slices); 6 slices walked in PAIRS
+// otherwise -- one barrier, one counted wait and one batch of fragment reads per 64-deep pair: a slice of these mid-size launches is
+// 128 MFMA cycles behind ~600 cycles of wait + barrier + DMA issue + ds_read latency (880 cycles per slice measured at K = 2048), so
+// halving the number of synchronisation points is worth more than the third slice of look-ahead it costs (round 5)
+template <bool DROP> struct ring_depth { static constexpr int value = DROP ? 4 : 6; };
 constexpr int B_BYTES = BN * BKS * 2;          // 8 KiB: one B slice
 
 __device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -39,6 +44,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
   constexpr int A_BYTES = BM * BKS * 2;        // one A slice: 8 or 4 KiB
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int AP = BM / 64;                  // 1-KiB A pieces per wave and slice (B: always 2)
+  constexpr int NST = ring_depth<DROP>::value;
   const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -148,6 +154,21 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
   };
 
+  if constexpr (!DROP) {
+    // ---- slices in pairs: pairs p + 1 in flight while pair p is multiplied, pair p + 2 requested into pair p - 1's slots behind the barrier
+    // (slices past the end -- an odd count, a one-pair product -- arrive as zeros: issue() fetches the zero chunk for them)
+    const int npairs = (nsteps + 1) >> 1;
+    issue(0); issue(1); issue(2); issue(3);
+    for (int pr = 0; pr < npairs; ++pr) {
+      if (pr + 1 < npairs) wait_vmcnt<2 * (AP + 2)>();      // the newer pair's pieces may stay in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // every wave's DMA of pair pr has landed; every wave has finished pair pr - 1
+      asm volatile("" ::: "memory");
+      if (pr + 2 < npairs) { issue(2 * pr + 4); issue(2 * pr + 5); }
+      compute((2 * pr) % NST);
+      compute((2 * pr + 1) % NST);
+    }
+  } else {
   // ---- prologue: NST-1 slices in flight
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
             acc[i][j][r] = ns_keep_el(dseed, row, col, drop_thr) ? acc[i][j][r] : 0.f;
           }
     }
+  }
   }
 
   if (gridDim.y > 1) {
@@ -231,11 +253,12 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   // 64-row tiles when 128-row tiles cover less than ~half of the CUs (the decoder-side GEMMs of a training step: 2816 rows x 512
   // columns = 88 tiles): such launches are bound by what ONE CU can fetch, and 176 workgroups move 3/4 of the bytes per CU
   const bool small = splits == 1 && tiles128 <= 384 && d->M > 64;
-  const size_t lds = NST * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
+  const bool dropv = d->drop_p > 0.f;
+  const size_t lds = (size_t)(dropv ? ring_depth<true>::value : ring_depth<false>::value) * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
   static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
   if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_ring_kernel<false, 128>, (const void*)ns_gemm_ring_kernel<true, 128>,
                                    (const void*)ns_gemm_ring_kernel<false, 64>, (const void*)ns_gemm_ring_kernel<true, 64>},
-                       64 * 1024, "ns_gemm (ring)"))
+                       96 * 1024, "ns_gemm (ring)"))
     return NS_ERR_HIP;
   if (small) {
     const int tiles = ((d->M + 63) / 64) * tn;
