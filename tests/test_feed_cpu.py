@@ -82,3 +82,44 @@ def test_header_parsing_and_shape_assertions(tmp_path):
     # slice starting beyond the file: zero rows, nothing staged
     pl = plan_read(RawSignal(p, 28, 301, 273), 6000)
     assert pl.rows == 0 and pl.nbytes == 0
+
+
+def test_loader_workers_come_from_a_forkserver_and_do_not_reimport_the_callers_script(tmp_path):
+    """DataLoader workers (reference: finetune.py:249, evaluation.py:126-127) are never forked from the process that drives the GPU
+    (utils.data_utils.worker_context: forkserver; a default-context loader is refused), and starting them does not re-import the
+    caller's main script: an UNGUARDED script that builds a loader -- what tools/run_recipe.py or a notebook cell calling
+    finetune.main() is -- must run its body once, with persistent workers serving two epochs."""
+    import subprocess
+    import sys
+    import textwrap
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    script = tmp_path / "unguarded_main.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, os
+        sys.path.insert(0, {root!r})
+        import torch
+        from neuspeech1_amd.synthetic import SyntheticProcessor
+        from neuspeech1_amd.weights import WHISPER_BASE
+        from tests.feed_cases import datasets, write_cases
+        from utils.data_utils import DataCollatorSpeechSeq2SeqWithPadding, worker_context, fork_safe_iter, start_worker_server
+        print("MAIN BODY RUNS", flush=True)
+        start_worker_server()
+        proc = SyntheticProcessor(WHISPER_BASE)
+        jl = write_cases({str(tmp_path)!r}, 208)
+        ds, ds_raw = datasets(jl, proc, 208)
+        coll = DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+        loader = torch.utils.data.DataLoader(ds_raw, batch_size=4, num_workers=2, collate_fn=coll, persistent_workers=True,
+                                             multiprocessing_context=worker_context(2))
+        for ep in range(2):
+            print("EPOCH", ep, sum(len(b["labels"]) for b in fork_safe_iter(loader)), flush=True)
+        try:
+            fork_safe_iter(torch.utils.data.DataLoader(ds, batch_size=4, num_workers=2, collate_fn=coll))
+        except RuntimeError as e:
+            print("REFUSED", str(e)[:40], flush=True)
+        print("FILE", __file__ is not None, flush=True)
+    """))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = r.stdout
+    assert out.count("MAIN BODY RUNS") == 1, out
+    assert "EPOCH 0 10" in out and "EPOCH 1 10" in out and "REFUSED DataLoader workers must come from" in out and "FILE True" in out, out

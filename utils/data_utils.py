@@ -114,13 +114,47 @@ def start_worker_server():
     forkserver.ensure_running()
 
 
+class _main_not_reimported:
+    """While workers start: hide `__main__`'s file / spec from multiprocessing.  A forkserver / spawn child otherwise RE-IMPORTS the
+    parent's main script (as `__mp_main__`) before it unpickles its task -- harmless for `python finetune.py` (guarded by
+    `if __name__ == "__main__"`), fatal for any caller that runs `finetune.main([...])` from an unguarded script or a notebook cell
+    (the child re-runs the training call: "An attempt has been made to start a new process before the current process has finished its
+    bootstrapping phase", seen with tools/run_recipe.py).  The workers need nothing from `__main__`: dataset and collator live in
+    importable modules (utils.reader, utils.data_utils), samplers stay in the parent."""
+
+    def __enter__(self):
+        import sys
+        self.m = sys.modules.get("__main__")
+        self.saved = (getattr(self.m, "__file__", None), getattr(self.m, "__spec__", None), hasattr(self.m, "__file__"))
+        if self.m is not None:
+            self.m.__file__ = None
+            self.m.__spec__ = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.m is not None:
+            f_, spec, had = self.saved
+            if had:
+                self.m.__file__ = f_
+            else:
+                try:
+                    del self.m.__file__
+                except AttributeError:
+                    pass
+            self.m.__spec__ = spec
+        return False
+
+
 def fork_safe_iter(loader):
-    """iter(loader).  Kept as the one place the CLIs start their workers: a loader with workers must have been built with
-    `multiprocessing_context=worker_context(n)` -- forking them from this (GPU-driving) process is refused."""
+    """iter(loader).  The one place the CLIs start their workers: a loader with workers must have been built with
+    `multiprocessing_context=worker_context(n)` -- forking them from this (GPU-driving) process is refused -- and the children do not
+    re-import the caller's main script."""
     if getattr(loader, "num_workers", 0) > 0:
         ctx = getattr(loader, "multiprocessing_context", None)
         method = ctx.get_start_method() if ctx is not None else None
         if method not in ("forkserver", "spawn"):
             raise RuntimeError("DataLoader workers must come from utils.data_utils.worker_context() (forkserver), never from a fork "
                                f"of the process that holds the GPU (start method: {method or 'fork (default)'})")
+        with _main_not_reimported():
+            return iter(loader)
     return iter(loader)
