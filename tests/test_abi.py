@@ -36,3 +36,27 @@ def test_attention_backward_workspace_rule():
     assert few > 0 and few % (64 * 8 * 44 * 64 * 4) == 0 and few // (64 * 8 * 44 * 64 * 4) <= 6
     for args in ((64, 8, 1500, 1500, 1), (64, 8, 44, 44, 1), (64, 8, 44, 200, 0), (64, 8, 100, 1500, 0), (64, 8, 200, 1500, 0)):
         assert f(*args) == 0, args
+
+
+def test_launch_list_recording_is_thread_local_and_launches_nothing():
+    """ops.recording / ops.LaunchList (generate.py replays them for generations too short for hipGraphs): while a list is being recorded on
+    a thread, entry points are appended with their marshalled arguments instead of being launched -- as a stream capture records instead of
+    executing -- and ONLY on that thread (the data feed's loader thread launches ns_feed_pack while the main thread may be recording)."""
+    import threading
+    import torch
+    from neuspeech1_amd import ops
+    t = torch.zeros(4, dtype=torch.int32)
+    lst = ops.LaunchList()
+    seen = {}
+    with ops.recording(lst):
+        ops.add_i32(t, 3)                      # on a CPU tensor: launching this would fail (no GPU here); recording must not call it
+        ops.zero_(torch.zeros(8))
+        th = threading.Thread(target=lambda: seen.setdefault("rec", getattr(ops._tls, "rec", None)))
+        th.start()
+        th.join()
+    assert seen["rec"] is None                # another thread does not see this thread's recording
+    assert [c[1] for c in lst.calls] == ["ns_add_i32", "ns_zero_spans"]
+    fn, name, args = lst.calls[0]
+    assert args[0] == t.data_ptr() and args[1] == 3
+    assert getattr(ops._tls, "rec", None) is None
+    assert int(t[0]) == 0                     # nothing ran

@@ -51,7 +51,8 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-@pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 12)])
+@pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 12),
+                                              ("ns_gemm_rowln.hip", "gemm_ln_kernel", 1), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel", 2)])
 def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, kernel, count):
     kernels = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
     assert len(kernels) == count, list(kernels)
@@ -84,7 +85,8 @@ def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, ke
 
 
 @pytest.mark.parametrize("src,kernel", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel"), ("ns_gemm_tn256.hip", "ns_gemm_tn256_kernel"),
-                                        ("ns_lora_bwd.hip", "lora_bwd_dudb_kernel"), ("ns_attn.hip", "attn_fwd_kernel")])
+                                        ("ns_lora_bwd.hip", "lora_bwd_dudb_kernel"), ("ns_attn.hip", "attn_fwd_kernel"),
+                                        ("ns_gemm_rowln.hip", "gemm_ln_kernel"), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel")])
 def test_hot_kernels_use_no_scratch(tmp_path, src, kernel):
     ks = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
     assert ks, src
@@ -215,3 +217,39 @@ def test_attention_forward_tiles_travel_by_lds_dma_with_one_barrier_per_tile(tmp
     assert i > 0
     vg = int(re.search(r"\.vgpr_count:\s+(\d+)", meta[i:i + 2000]).group(1))
     assert vg <= 128, vg
+
+
+@pytest.mark.parametrize("src,kernel,count,pieces", [("ns_gemm_rowln.hip", "gemm_ln_kernel", 1, 5), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel", 2, 6)])
+def test_round5_gemm_k_loops_wait_counted_and_fit_two_waves_per_simd(tmp_path, src, kernel, count, pieces):
+    """ns_gemm_ln / ns_gemm_p4 (round 5): the K loop -- twelve 32-deep steps unrolled, 32 MFMAs and ONE barrier each -- holds only the
+    hand-counted wait that lets the newest step's pieces travel on (never vmcnt(0)), requests its operands by LDS-DMA (`pieces` per
+    wave and step), and the kernel keeps to the 256 registers that put two waves on a SIMD."""
+    asm = _asm(src, tmp_path)
+    ks = {k: v for k, v in _kernels(asm).items() if kernel in k}
+    assert len(ks) == count, list(ks)
+    for name, body in ks.items():
+        text = "\n".join(body)
+        found = False
+        for m in re.finditer(r"\n\.(LBB\d+_\d+):[^\n]*Inner Loop Header: Depth=1", text):
+            # the loop = the header block and every following block annotated "in Loop: Header=<this one>" (a step that may lie past
+            # the end of K is guarded, so the twelve unrolled steps are separate basic blocks)
+            hdr = m.group(1).replace("LBB", "BB")
+            rest = text[m.end():]
+            stop = None
+            for lab in re.finditer(r"\n\.LBB\d+_\d+:([^\n]*)", rest):
+                if f"Header={hdr} " not in lab.group(1) + " ":
+                    stop = lab.start()
+                    break
+            loop = rest[:stop] if stop is not None else rest
+            n_mfma = len(re.findall(r"v_mfma_f32_16x16x32", loop))
+            if n_mfma < 12 * 32:
+                continue
+            found = True
+            assert not re.search(r"scratch_(load|store)", loop), name
+            assert "vmcnt(0)" not in loop, name
+            assert len(re.findall(r"s_barrier", loop)) == 12, name
+            assert len(re.findall(r"buffer_load_dwordx4 [^\n]* lds", loop)) == 12 * pieces, name
+        assert found, f"{name}: K loop not found"
+        i = asm.find(f".name:           {name}")
+        assert i > 0, name
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", asm[i:i + 2000]).group(1)) <= 256, name
