@@ -493,12 +493,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
   // skinny-N tiles (128x32) also serve small-M decode GEMMs: 4x more workgroups than 128x128 tiles when M <= 1024
   // (large-M N = 96 -- the stacked q|k|v LoRA bottleneck -- goes to the 128-wide tile: one pass over A, and one dropout
   // hash per element, instead of three 32-wide column tiles each re-reading and re-masking it)
-  // (M in (256, 1024] with N >= 1024 -- the q|k|v and fc1 projections of a beam-search step, 640 rows -- has too many 32 x 32 tiles for the
-  // small-M kernel and ran on the 128 x 32 register-staged tile at ~22 us; the 64 x 128 LDS-DMA ring takes it, NS_MIDM_RING=0 for A/B runs)
-  static const bool midm_ring = [] { const char* e = getenv("NS_MIDM_RING"); return !e || atoi(e) != 0; }();
-  const bool midm = midm_ring && !tn && d->M > 256 && d->M <= 1024 && d->N >= 1024 && d->N <= 4096 && d->N % 8 == 0 && g_use_ring == 1 &&
-                    !(d->flags & NS_GEMM_DROP_A) && d->splits <= 1 && !ns_gemm_smallm_ok(d);
-  const bool skinny = !tn && !midm && ((d->N <= 96 && !(d->M >= 4096 && d->N > 32)) || (d->M <= 1024 && d->N <= 4096));
+  const bool skinny = !tn && ((d->N <= 96 && !(d->M >= 4096 && d->N > 32)) || (d->M <= 1024 && d->N <= 4096));
   const bool drop = d->drop_p > 0.f;
   const int bn = skinny ? 32 : 128;
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + bn - 1) / bn);
