@@ -27,9 +27,11 @@ GFLOP_PER_SAMPLE = {208: 239.67, 273: 242.06}
 # fwd+bwd" is measured on
 ENC_GFLOP_PER_SAMPLE = {208: 213.37, 273: 215.76}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
-# the dominant kernel: the phase-interleaved 256 x 256 GEMM in its two forms -- one tile per workgroup (ns_gemm_p8_kernel: launches of < 1024
-# tiles, the position-row epilogue) and persistent (ns_gemm_p8s_kernel: >= 1024 tiles) -- one tile arithmetic, one "nt256" class in the
-# event-timed leg; in the rocprof stats its average launch = all ns_gemm_p8*_kernel rows together
+# the dominant kernel: the phase-interleaved 256 x 256 GEMM in its two forms -- one tile per workgroup (ns_gemm_p8_kernel: launches of < 700
+# tiles, the position-row epilogue) and persistent (ns_gemm_p8s_kernel: >= 700 tiles, NS_P8S_MIN_TILES in csrc/ns_gemm.hip, part of the
+# counter file's source hash) -- one tile arithmetic, one "nt256" class in the event-timed leg; in the rocprof stats its average launch = all
+# ns_gemm_p8*_kernel rows together.  Since round 5 the class has 52 launches per step (68 before): out_proj + LayerNorm run as ns_gemm_ln
+# ("rowln" in step_share), the six decoder layers' cross K|V projections and their input gradients as one launch each
 DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
 PMC_FILE = "profiles/r5_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 DECODE_PMC_FILE = "profiles/r5_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
