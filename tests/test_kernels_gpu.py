@@ -1106,3 +1106,47 @@ def test_gemm_ln_is_bitwise_the_two_launches(ops, dev, M, K, K2):
     h = R[sl] + y.half().float()
     close(H1[sl], h, 2e-2, 2e-3, "H32 vs torch")
     close(x1[sl], F.layer_norm(h, (N,), gamma, beta, 1e-5), 2e-2, 1e-2, "x16 vs torch")
+
+
+def test_zero_spans_and_counter_kernels(ops, dev):
+    """ns_zero_spans (what clears the gradient buffer / split-K targets of a captured step and every engine allocation) and ns_add_i32
+    (the LoRA-dropout step counter): 16-B body + dword tail, more than 8 spans per call, neighbours untouched, empty tensors skipped."""
+    sizes = [1, 3, 4, 5, 1023, 4096, 14_650_000 // 4, 7, 64, 2, 9, 33]
+    bufs = [torch.full((n + 8,), 7.0, device=dev) for n in sizes]
+    views = [b[4:4 + n] for b, n in zip(bufs, sizes)]          # (a 16-byte aligned start: the ABI's contract)
+    ops.zero_(*views, None, torch.empty(0, device=dev))
+    torch.cuda.synchronize()
+    for b, n in zip(bufs, sizes):
+        assert float(b[4:4 + n].abs().max()) == 0.0, n
+        assert float(b[:4].min()) == 7.0 and float(b[4 + n:].min()) == 7.0, n
+    h = torch.full((5, 3), 1.0, device=dev, dtype=torch.float16)          # 30 bytes is not a multiple of 4: refused loudly, not half-cleared
+    from neuspeech1_amd.lib import NeuSpeechHipError
+    with pytest.raises(NeuSpeechHipError, match="ns_zero_spans"):
+        ops.zero_(h)
+    c = torch.tensor([5, 40], device=dev, dtype=torch.int32)
+    ops.add_i32(c, 1)
+    ops.add_i32((c, 1), -3)
+    assert c.tolist() == [6, 37]
+    z = ops.zeros(3, 5, device=dev, dtype=torch.int64)
+    assert z.shape == (3, 5) and int(z.abs().sum()) == 0
+
+
+def test_gemm_ln_refuses_what_it_does_not_build(ops, dev):
+    """ns_gemm_ln: N != 512, K % 64 != 0, extra outputs or flags come back as errors (the engine then takes the two launches)."""
+    from neuspeech1_amd.lib import NeuSpeechHipError
+    assert not ops.gemm_ln_supported(96000, 1280, 1280, 32) and not ops.gemm_ln_supported(96000, 512, 544, 0)
+    assert not ops.gemm_ln_supported(512, 512, 512, 0) and not ops.gemm_ln_supported(96000, 512, 512, 96)
+    M, N, K = 2048, 512, 512
+    A, W = rnd((M, K), dev), rnd((N, K), dev, 0.05)
+    R, H = rnd((M, N), dev, 1.0, torch.float32), torch.empty(M, N, device=dev)
+    g, b_ = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    x = torch.empty(M, N, device=dev, dtype=torch.float16)
+    base = dict(A=A, am=ops.rowmap(K), K=K, B=W, ldb=K, M=M, N=N, R32=R, H32=H, h32m=ops.rowmap(N), gamma=g, beta=b_, x16=x, ldx=N)
+    ops.gemm_ln(**base)                                             # the plain call works
+    for bad in (dict(flags=ops.NS_GEMM_GELU), dict(C16=x, c16m=ops.rowmap(N)), dict(drop_p=0.05), dict(K=K - 32)):
+        with pytest.raises(NeuSpeechHipError, match="ns_gemm_ln"):
+            ops.gemm_ln(**{**base, **bad})
+    torch.cuda.synchronize()
+    ref = R + (A.float() @ W.float().t()).half().float()
+    close(H, ref, 2e-2, 2e-3, "H32")
+    close(x, F.layer_norm(ref, (N,), g, b_, 1e-5), 2e-2, 1e-2, "x16")
