@@ -522,7 +522,9 @@ class MegWhisperEngine:
         b["enc_st"] = (f32(M), f32(M))
         ndl = dims.dec_layers if train else 1
         # cross-attention K | V of the encoder rows, per decoder layer: (tensor, column offset) + row stride b["kv_ld"]
-        if train and self.ckv_batch:
+        # (only while the stacked buffer stays below 2 GiB: the 256 x 256 GEMM addresses its operands with 32-bit byte offsets, and the input
+        # gradient reads the stacked d(K|V) as its A operand -- whisper-large-v2's 32 layers x 2560 columns would fall back to slower kernels)
+        if train and self.ckv_batch and M * ndl * 2 * d * 2 < 0x7FFF0000:
             b["kv_all"] = h16(M, ndl * 2 * d)
             b["kv_c"] = [(b["kv_all"], i * 2 * d) for i in range(ndl)]
             b["kv_ld"] = ndl * 2 * d
@@ -543,7 +545,7 @@ class MegWhisperEngine:
             nws = ops.attn_bwd_workspace_bytes(B, H, S, S) if os.environ.get("NS_ATTN_TWO_PASS") != "1" else 0
             b["attn_ws"] = torch.empty(nws, device=dev, dtype=torch.uint8) if nws else None
             b["denc32"] = f32(M, d)
-            if self.ckv_batch:
+            if "kv_all" in b:
                 b["dkv_all"] = h16(M, ndl * 2 * d)
                 b["dkv_c"] = [(b["dkv_all"], i * 2 * d) for i in range(ndl)]
             else:
