@@ -162,6 +162,10 @@ void ns_debug_set_ring(int on);
  * variable sets the same mask): 1 plain, 2 GELU, 4 GELU + side product, 8 fp32 residual, 16 x gelu' / x P16, 32 the same with the adapter
  * product under dropout, 64 plain with the adapter product under dropout.  Outputs are bit-identical whatever the mask. */
 void ns_debug_set_p4(int mask);
+/* A/B knob (NS_AD_SELF sets the same): which kernel ns_attn_decode's ancestry-layout launches (the decode loop's self-attention) take:
+ * 1 (default) = one wave per (row, head) when groups * H > 2048, else the four-wave kernel of the cross-attention layout; 0 = never the
+ * wave-per-head form; 2 = always.  Outputs agree up to fp32 summation order. */
+void ns_debug_set_ad_self(int mode);
 
 /* ------------------------------------------------------------------------
  * LayerNorm over the fp32 residual stream (eps 1e-5, affine), one row = d

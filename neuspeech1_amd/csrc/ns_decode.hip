@@ -9,6 +9,7 @@
 // (beam search), HF:generation/logits_process.py:306-414, :1073-1141, :1816-1906 and the cache reorder
 // utils/load_model.py:1353-1360 (here: an int32 ancestry table instead of re-gathering K/V tensors).
 #include "ns_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -148,6 +149,116 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ns_attn_decode_d
       L += red[w][qi][D + 1] * sc;
     }
     ((half_t*)p.O)[(long long)(grp * NQ + qi) * p.ldo + h * D + dd] = (half_t)(v / L);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- self-attention, one wave per head
+// The decode loop's SELF-attention (ancestry layout, one query per row, <= a few hundred keys): the four-wave form above
+// gives every (row, head) 32 subgroups, of which a 68-key row fills 2 1/8 rounds -- and every wave runs the whole instruction
+// stream whether its subgroups hold a key or not: at 640 rows x 8 heads that is 20 480 waves of ~400 instructions for 350 k
+// keys (16.8 us per layer in the beam-5 profile, 7 us at 128 rows).  Here ONE WAVE owns a (row, head): its 8 subgroups walk
+// the keys j = sg, sg + 8, ..., AS_KU keys per iteration (the ancestry entries of an iteration are loaded together, then
+// its 2 AS_KU rows), the subgroups meet by shuffles, nothing goes through LDS and nothing waits at a barrier.  A workgroup is
+// four such waves = four heads of one row.
+#ifndef NS_AS_KU
+#define NS_AS_KU 4
+#endif
+__global__ __launch_bounds__(256) void attn_self_kernel(const ns_attn_decode_desc p) {
+  constexpr int KU = NS_AS_KU;
+  const int Lk = p.kv_len_dev ? *p.kv_len_dev : p.Lk;
+  const int lane = threadIdx.x & 63, sg = lane >> 3, l8 = lane & 7;
+  const int grp = blockIdx.x, h = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (h >= p.H) return;                                   // (no barrier below)
+  const half_t* Kb = (const half_t*)p.K + h * D + l8 * 8;
+  const half_t* Vb = (const half_t*)p.V + h * D + l8 * 8;
+  const int* anc = p.anc + (long long)grp * p.anc_ld;
+  // the ancestry entries of an iteration are requested one iteration ahead (the first ones before anything else)
+  int a[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) a[u] = anc[min(sg + 8 * u, Lk - 1)];
+  const half_t* const Kn = p.Knew ? (const half_t*)p.Knew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
+  const half_t* const Vn = p.Knew ? (const half_t*)p.Vnew + (long long)grp * p.ldnew + h * D + l8 * 8 : nullptr;
+  half8 knew, vnew;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { knew[e] = (half_t)0.f; vnew[e] = (half_t)0.f; }
+  if (Kn) {                                               // (stored into the cache at the end: a store in front of the loop is waited for)
+    knew = *(const half8*)Kn;
+    vnew = *(const half8*)Vn;
+  }
+  float q[8], acc[8], m = -INFINITY, l = 0.f;
+  {
+    const half8 qv = *(const half8*)((const half_t*)p.Q + (long long)grp * p.ldq + h * D + l8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q[e] = (float)qv[e]; acc[e] = 0.f; }
+  }
+  for (int j0 = sg; j0 < Lk; j0 += 8 * KU) {              // key j0 is valid for this subgroup: its running max is finite
+    // branch-free: a lane past the end re-reads the last key (its score is masked below), so that the 2 KU rows of an
+    // iteration are in flight together.  The newest position comes from this step's projection rows (in registers; its
+    // cache row -- slot 0 of that position, whatever it holds -- is loaded and dropped).
+    half8 kv[KU], vv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int j = min(j0 + 8 * u, Lk - 1);
+      const bool fresh = Kn && j == Lk - 1;
+      const long long r = (long long)j * p.kv_pos_stride + (fresh ? 0 : a[u]);
+      const half8 kl = *(const half8*)(Kb + r * p.ldk), vl = *(const half8*)(Vb + r * p.ldv);
+      kv[u] = fresh ? knew : kl;
+      vv[u] = fresh ? vnew : vl;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) a[u] = anc[min(j0 + 8 * (KU + u), Lk - 1)];
+    float s[KU], mn = m;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += q[e] * (float)kv[u][e];
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      s[u] = j0 + 8 * u < Lk ? d : -INFINITY;
+      mn = fmaxf(mn, s[u]);
+    }
+    const float alpha = __expf(m - mn);
+    m = mn;
+    float pw[KU], ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { pw[u] = __expf(s[u] - mn); ps += pw[u]; }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = acc[e] * alpha;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) t += pw[u] * (float)vv[u][e];
+      acc[e] = t;
+    }
+  }
+  // the 8 subgroups (lanes with equal l8) meet
+  float M = m;
+  M = fmaxf(M, __shfl_xor(M, 8, 64));
+  M = fmaxf(M, __shfl_xor(M, 16, 64));
+  M = fmaxf(M, __shfl_xor(M, 32, 64));
+  const float sc = m == -INFINITY ? 0.f : __expf(m - M);   // a subgroup that saw no key contributes nothing
+  float L = l * sc;
+  L += __shfl_xor(L, 8, 64);
+  L += __shfl_xor(L, 16, 64);
+  L += __shfl_xor(L, 32, 64);
+  half8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = acc[e] * sc;
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    o[e] = (half_t)(v / L);
+  }
+  if (sg == 0) {
+    *(half8*)((half_t*)p.O + (long long)grp * p.ldo + h * D + l8 * 8) = o;
+    if (Kn) {
+      const long long r = (long long)(Lk - 1) * p.kv_pos_stride + p.slot0 + grp;
+      *(half8*)((half_t*)p.K + h * D + l8 * 8 + r * p.ldk) = knew;
+      *(half8*)((half_t*)p.V + h * D + l8 * 8 + r * p.ldv) = vnew;
+    }
   }
 }
 
@@ -948,6 +1059,20 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restr
 
 }  // namespace
 
+// Which kernel the ancestry-layout launches (the decode loop's self-attention) take: NS_AD_SELF / ns_debug_set_ad_self =
+//   1 (default) by size: one wave per (row, head) once the four-wave form no longer fits the chip in one round (8 workgroups
+//     per CU = 2048; tools/probe/attn_self_ab.py: 640 rows x 8 heads 8.3 / 14.2 / 21.1 us against 12.0 / 16.2 / 25.2 at
+//     8 / 36 / 68 keys; 128 rows 4.7 / 6.5 / 7.8 against 4.1 / 5.9 / 7.4),  0 never,  2 always (tests).
+static int g_ad_self = -1;
+extern "C" void ns_debug_set_ad_self(int mode) { g_ad_self = mode < 0 ? 1 : mode; }
+static bool self_wave_form(const ns_attn_decode_desc* d) {
+  if (g_ad_self < 0) {
+    const char* e = getenv("NS_AD_SELF");
+    g_ad_self = e ? atoi(e) : 1;
+  }
+  return g_ad_self >= 2 || (g_ad_self == 1 && (long long)d->groups * d->H > 2048);
+}
+
 extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
   NS_CHECK_ARG(d && d->Q && d->K && d->V && d->O, "ns_attn_decode: null pointer");
   NS_CHECK_ARG(d->head_dim == 64, "ns_attn_decode: head_dim must be 64");
@@ -959,6 +1084,11 @@ extern "C" int ns_attn_decode(const ns_attn_decode_desc* d, void* stream) {
   NS_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0, "ns_attn_decode: strides must be multiples of 8");
   dim3 grid(d->groups, d->H);
   hipStream_t st = (hipStream_t)stream;
+  if (d->anc && d->nq == 1 && d->ldo % 8 == 0 && self_wave_form(d)) {   // self-attention: one wave per (row, head)
+    hipLaunchKernelGGL(attn_self_kernel, dim3(d->groups, (d->H + 3) / 4), dim3(256), 0, st, *d);
+    NS_CHECK_LAUNCH("ns_attn_decode");
+    return NS_OK;
+  }
 #define NS_AD(NQ_)                                                                                                \
   case NQ_: {                                                                                                     \
     hipLaunchKernelGGL(attn_decode_kernel<NQ_>, grid, dim3(256), 0, st, *d);                                       \

@@ -187,6 +187,7 @@ SIGNATURES = {
     "ns_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ns_debug_set_ring": (None, [C.c_int]),
     "ns_debug_set_p4": (None, [C.c_int]),
+    "ns_debug_set_ad_self": (None, [C.c_int]),
     "ns_gemm_ln_supported": (C.c_int, [_i, _i, _i, _i]),
     "ns_gemm_ln": (C.c_int, [C.POINTER(GemmLnDesc), _vp]),
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

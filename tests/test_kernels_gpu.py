@@ -742,11 +742,21 @@ def test_attn_decode_cross_layout(ops, dev, nq, Lk):
     close(O, ref, 2e-3, 2e-3, "attn_decode")
 
 
-@pytest.mark.parametrize("Lk", [1, 9, 68])
-def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk):
+@pytest.fixture
+def ad_self_form(request):
+    from neuspeech1_amd import lib
+    lib.load().ns_debug_set_ad_self(request.param)
+    yield request.param
+    lib.load().ns_debug_set_ad_self(1)
+
+
+@pytest.mark.parametrize("ad_self_form", [2, 0], indirect=True, ids=["wave_per_head", "four_waves"])
+@pytest.mark.parametrize("Lk,H", [(1, 4), (9, 4), (68, 4), (68, 6), (300, 6), (448, 8)])
+def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk, H, ad_self_form):
     """self-attention over the position-major K/V cache: row r at position j reads cache row anc[r][j] (beam ancestry),
-    the live length comes from device memory."""
-    rows, H, d, Lmax = 10, 4, 64, 80
+    the live length comes from device memory.  Both kernels of the layout: one wave per (row, head) -- the default; heads
+    not a multiple of the four waves of a workgroup, key counts over several iterations -- and the four-wave form."""
+    rows, d, Lmax = 10, 64, max(80, Lk + 3)
     Q = rnd((rows, 3 * H * d), dev, 0.6, seed=3)
     cache = rnd((Lmax * rows, 2 * H * d), dev, 0.7, seed=4)
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -1150,3 +1160,4 @@ def test_gemm_ln_refuses_what_it_does_not_build(ops, dev):
     ref = R + (A.float() @ W.float().t()).half().float()
     close(H, ref, 2e-2, 2e-3, "H32")
     close(x, F.layer_norm(ref, (N,), g, b_, 1e-5), 2e-2, 1e-2, "x16")
+
