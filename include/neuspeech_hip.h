@@ -243,12 +243,12 @@ int ns_colsum(const void* a16, float* out32, int rows, int cols, int ld, float a
  * Trainer runs it: zero_grad, forward, backward, optimizer) is replayed from hipGraphs, and a captured memset NODE was not
  * reliably ordered against the kernel nodes around it under back-to-back replays (see ns_orth_reg).  ns_zero_spans clears
  * up to NS_ZERO_MAX_SPANS buffers in one launch (`spans` is a HOST array, copied into the launch arguments; each span
- * 16-byte aligned, a multiple of 4 bytes); ns_add_i32 advances a device counter (the LoRA-dropout step counter that
- * ns_gemm_desc.seed_dev points at). */
+ * 16-byte aligned, a multiple of 4 bytes); ns_add_i32 adds v to n <= 64 consecutive device counters (n = 1: the LoRA-dropout
+ * step counter that ns_gemm_desc.seed_dev points at; n = 2: the decode loop's position / length pair, one launch per step). */
 #define NS_ZERO_MAX_SPANS 8
 typedef struct { void* p; size_t bytes; } ns_span;
 int ns_zero_spans(const ns_span* spans, int n, void* stream);
-int ns_add_i32(int32_t* counter_dev, int32_t v, void* stream);
+int ns_add_i32(int32_t* counter_dev, int32_t n, int32_t v, void* stream);
 
 /* batched fp32 -> fp16 operand refresh after an optimizer step:
  * dst[r][c] = scale*src[r][c]  or (transpose) dst[c][r] = scale*src[r][c] */

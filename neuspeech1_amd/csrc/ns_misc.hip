@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void zero_spans_kernel(const zero_spans_arg a)
     for (size_t i = (n16 << 2) + threadIdx.x; i < (sp.bytes >> 2); i += blockDim.x) p4[i] = 0u;
   }
 }
-__global__ void add_i32_kernel(int32_t* p, int32_t v) { *p += v; }
+__global__ void add_i32_kernel(int32_t* p, int32_t n, int32_t v) { if ((int)threadIdx.x < n) p[threadIdx.x] += v; }
 
 }  // namespace
 
@@ -531,9 +531,9 @@ extern "C" int ns_zero_spans(const ns_span* spans, int n, void* stream) {
   return NS_OK;
 }
 
-extern "C" int ns_add_i32(int32_t* counter_dev, int32_t v, void* stream) {
-  NS_CHECK_ARG(counter_dev, "ns_add_i32: null pointer");
-  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, v);
+extern "C" int ns_add_i32(int32_t* counter_dev, int32_t n, int32_t v, void* stream) {
+  NS_CHECK_ARG(counter_dev && n >= 1 && n <= 64, "ns_add_i32: null pointer or n=%d outside 1 .. 64", n);
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev, n, v);
   NS_CHECK_LAUNCH("ns_add_i32");
   return NS_OK;
 }

@@ -127,6 +127,9 @@ class Generator:
         nl = dims.dec_layers
         kvc = [torch.zeros(max_len * Bp, 2 * d, device=dev, dtype=F16) for _ in range(nl)]
         anc = [torch.zeros(Bp, max_len, device=dev, dtype=torch.int32) for _ in range(2)]
+        if nb == 1:     # greedy rows never change slots: the ancestry table is the identity, written once (no ns_anc_update per step)
+            for a_ in anc:
+                a_.copy_(torch.arange(Bp, device=dev, dtype=torch.int32).unsqueeze(1).expand(Bp, max_len))
         h = [torch.empty(Bp, d, device=dev, dtype=F32) for _ in range(2)]
         x16 = torch.empty(Bp, d, device=dev, dtype=F16)
         qkv = torch.empty(Bp, 3 * d, device=dev, dtype=F16)
@@ -209,8 +212,9 @@ class Generator:
             With `ctr` (device int32 [t, t+1]) the position is read on the device."""
             c0 = ctr
             c1 = (ctr, 1) if ctr is not None else None
-            ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t, cur_dev=c0)
-            anc.reverse()
+            if nb > 1:
+                ops.anc_update(anc[0], anc[1], parent, Bp, max_len, t, cur_dev=c0)
+                anc.reverse()
             a = anc[0]
             ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t, pos0_dev=c0)
             if nsplit == 1:
@@ -307,8 +311,7 @@ class Generator:
 
                         def feed():
                             step(next_tok, cur, parent, ctr)
-                            ops.add_i32(ctr, 1)
-                            ops.add_i32((ctr, 1), 1)
+                            ops.add_i32(ctr, 1, n=2)
                         for _ in range(2):
                             if as_list:
                                 gs, gt = ops.LaunchList(), ops.LaunchList()

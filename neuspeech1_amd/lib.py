@@ -201,7 +201,7 @@ SIGNATURES = {
     "ns_colsum": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "ns_cast_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_zero_spans": (C.c_int, [C.POINTER(Span), _i, _vp]),
-    "ns_add_i32": (C.c_int, [_vp, C.c_int32, _vp]),
+    "ns_add_i32": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "ns_adalora_fold_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_adalora_fold_jobs": (C.c_int, [_vp, _i, _vp]),
     "ns_gemm_side_supported": (C.c_int, [_i, _i, _i]),

@@ -279,8 +279,9 @@ def zeros(*shape, device, dtype):
     return t
 
 
-def add_i32(counter_dev, v=1):
-    _call("ns_add_i32", ptr(counter_dev), int(v))
+def add_i32(counter_dev, v=1, n=1):
+    """v added to n consecutive int32 device counters in one launch"""
+    _call("ns_add_i32", ptr(counter_dev), int(n), int(v))
 
 
 def make_cast_jobs(jobs, device) -> tuple[torch.Tensor, int]:

@@ -57,6 +57,6 @@ def test_launch_list_recording_is_thread_local_and_launches_nothing():
     assert seen["rec"] is None                # another thread does not see this thread's recording
     assert [c[1] for c in lst.calls] == ["ns_add_i32", "ns_zero_spans"]
     fn, name, args = lst.calls[0]
-    assert args[0] == t.data_ptr() and args[1] == 3
+    assert args[0] == t.data_ptr() and args[1] == 1 and args[2] == 3     # (pointer, n, v)
     assert getattr(ops._tls, "rec", None) is None
     assert int(t[0]) == 0                     # nothing ran

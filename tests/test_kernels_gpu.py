@@ -1137,6 +1137,10 @@ def test_zero_spans_and_counter_kernels(ops, dev):
     ops.add_i32(c, 1)
     ops.add_i32((c, 1), -3)
     assert c.tolist() == [6, 37]
+    ops.add_i32(c, 2, n=2)                  # the decode loop's position / length pair: one launch
+    assert c.tolist() == [8, 39]
+    with pytest.raises(NeuSpeechHipError, match="ns_add_i32"):
+        ops.add_i32(c, 1, n=65)
     z = ops.zeros(3, 5, device=dev, dtype=torch.int64)
     assert z.shape == (3, 5) and int(z.abs().sum()) == 0
 
