@@ -253,3 +253,29 @@ def test_round5_gemm_k_loops_wait_counted_and_fit_two_waves_per_simd(tmp_path, s
         i = asm.find(f".name:           {name}")
         assert i > 0, name
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", asm[i:i + 2000]).group(1)) <= 256, name
+
+
+def test_decode_self_attention_loads_are_branch_free_and_counted(tmp_path):
+    """attn_self_kernel (one wave per (row, head)): no scratch, no LDS, no barrier; inside the key loop the rows of an iteration are
+    requested together -- no branch between the first K / V load and the last (a conditional load per key serialised the four
+    round trips in the first build) -- and the first wait of the loop is a COUNTED one (the next iteration's ancestry entries stay
+    in flight behind the rows)."""
+    ks = {k: v for k, v in _kernels(_asm("ns_decode.hip", tmp_path)).items() if "attn_self_kernel" in k}
+    assert len(ks) == 1
+    body = next(iter(ks.values()))
+    text = "\n".join(body)
+    assert not re.search(r"scratch_(load|store)", text) and "s_barrier" not in text and not re.search(r"\bds_(read|write)", text)
+    ops = [l.split(";")[0].split() for l in body]
+    ops = [o for o in ops if o and not o[0].startswith(".") and not o[0].endswith(":")]
+    # the densest run of 16-B loads: the 2 * NS_AS_KU row loads of one iteration
+    best, cur, start = 0, 0, 0
+    for i, o in enumerate(ops):
+        if o[0] == "global_load_dwordx4":
+            cur += 1
+            if cur > best:
+                best, end = cur, i
+        elif o[0].startswith("s_cbranch") or o[0] == "s_branch":
+            cur = 0
+    assert best >= 8, f"only {best} row loads issued without a branch between them"
+    waits = [o for o in ops[end + 1:] if o[0] == "s_waitcnt" and "vmcnt" in " ".join(o)]
+    assert waits and "vmcnt(0)" not in " ".join(waits[0]), waits[:1]
