@@ -6,6 +6,11 @@
 // rows a half wave touches per transposed read then tile the 64 banks exactly (conflict-free).
 // Tiles: <128,128> (conv weight grads), <32,128> (LoRA dA: r x K), <128,32> (LoRA dB: N x r).  The reduction is split
 // over gridDim.z and accumulated with fp32 atomics in the full-rate shape (128 contiguous bytes per half wave).
+// Pipeline (round 5): the operands of THREE 64-row steps are in flight in registers (three register stages, the loop unrolled by
+// three so that they are named statically), two LDS buffers, one bare s_barrier per step behind the wave's own LDS stores
+// (__syncthreads() is a fence: hipcc drains the vector-memory queue in front of it, i.e. every step waited for the loads it had
+// just issued -- a memory round trip per 64 rows, 3.3 TB/s over the adapters' dA launches).  The store of step t + 1 waits for
+// ITS loads only (the queue is in order; hipcc counts).  Same products in the same order: results are bitwise those of round 4.
 #include "ns_common.h"
 #include <mutex>
 
@@ -73,7 +78,9 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
   const int ca = tid % CA, cb = tid % CB;
   const int cola = min(i0 + ca * 8, p.M - 8), colb = min(j0 + cb * 8, p.N - 8);
 
-  uint4 ra[LA], rb[LB];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  struct stage { u32x4 a[LA]; u32x4 b[LB]; };
+  stage R[3];
   auto row_off = [&](const ns_rowmap& map, int rl) __attribute__((always_inline)) -> long long {
     if (map.seg_rows > 0) {
       int w = within + rl, s = seg;
@@ -82,39 +89,63 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
     }
     return (long long)(within + rl) * map.ld;
   };
-  auto load = [&](int step) __attribute__((always_inline)) {
+  // load: the 16-B pieces of one step, UNCONDITIONALLY (a row past the end of the range re-reads the range's last row: a
+  // conditional load is a branch, and behind branches hipcc waits for an empty vector-memory queue instead of counting);
+  // store: those rows become zeros, the dropout mask is applied, the pieces go to LDS
+  auto load = [&](int step, stage& rg) __attribute__((always_inline)) {
     const int klen = min(BKM, k_end - k_begin - step * BKM);
 #pragma unroll
     for (int it = 0; it < LA; ++it) {
-      const int rl = tid / CA + it * (NTH / CA);
-      ra[it] = rl < klen ? *(const uint4*)((const half_t*)p.A + row_off(p.am, rl) + cola) : make_uint4(0, 0, 0, 0);
+      const int rl = min(tid / CA + it * (NTH / CA), klen - 1);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rg.a[it]) : "v"((const half_t*)p.A + row_off(p.am, rl) + cola) : "memory");
     }
 #pragma unroll
     for (int it = 0; it < LB; ++it) {
-      const int rl = tid / CB + it * (NTH / CB);
-      uint4 v = rl < klen ? *(const uint4*)((const half_t*)p.B + row_off(p.bm, rl) + colb) : make_uint4(0, 0, 0, 0);
-      if (DROP) {
-        const uint32_t grow = (uint32_t)(k_begin + step * BKM + rl);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t m[4];
-        ns_keep_masks(ns_drop_word(dseed, grow, (uint32_t)colb >> 2), drop_thr, m[0], m[1]);
-        ns_keep_masks(ns_drop_word(dseed, grow, ((uint32_t)colb >> 2) + 1), drop_thr, m[2], m[3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] &= m[e];
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-      rb[it] = v;
+      const int rl = min(tid / CB + it * (NTH / CB), klen - 1);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rg.b[it]) : "v"((const half_t*)p.B + row_off(p.bm, rl) + colb) : "memory");
     }
     within += BKM;
     if (p.am.seg_rows > 0 && within >= p.am.seg_rows) { within -= p.am.seg_rows; seg += 1; }
   };
-  auto store = [&](int buf) __attribute__((always_inline)) {
+  // The loads are inline assembly (hipcc's own counting degrades to vmcnt(0) in this control flow: found in the ISA), so the wait in
+  // front of a stage's store is written here: the queue is in order, `later` = the stages requested after this one that may stay
+  // in flight (block-uniform).  The empty asm statements tie the stage's registers to the wait: no use may be scheduled above it.
+  auto landed = [&](stage& rg, int later) __attribute__((always_inline)) {
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (LA + LB)) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LA + LB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int it = 0; it < LA; ++it)
-      *(uint4*)(As + buf * A_BYTES + (tid / CA + it * (NTH / CA)) * SA + ca * 16) = ra[it];
+    for (int it = 0; it < LA; ++it) asm volatile("" : "+v"(rg.a[it]));
 #pragma unroll
-    for (int it = 0; it < LB; ++it)
-      *(uint4*)(Bs + buf * B_BYTES + (tid / CB + it * (NTH / CB)) * SB + cb * 16) = rb[it];
+    for (int it = 0; it < LB; ++it) asm volatile("" : "+v"(rg.b[it]));
+  };
+  auto store = [&](int buf, stage& rg, int step) __attribute__((always_inline)) {
+    landed(rg, min(2, nsteps - 1 - step));
+    const int klen = min(BKM, k_end - k_begin - step * BKM);
+#pragma unroll
+    for (int it = 0; it < LA; ++it) {
+      const int rl = tid / CA + it * (NTH / CA);
+      *(u32x4*)(As + buf * A_BYTES + rl * SA + ca * 16) = rl < klen ? rg.a[it] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int it = 0; it < LB; ++it) {
+      const int rl = tid / CB + it * (NTH / CB);
+      u32x4 v = rl < klen ? rg.b[it] : u32x4{0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint32_t grow = (uint32_t)(k_begin + step * BKM + rl);
+        uint32_t m[4];
+        ns_keep_masks(ns_drop_word(dseed, grow, (uint32_t)colb >> 2), drop_thr, m[0], m[1]);
+        ns_keep_masks(ns_drop_word(dseed, grow, ((uint32_t)colb >> 2) + 1), drop_thr, m[2], m[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] &= m[e];
+      }
+      *(u32x4*)(Bs + buf * B_BYTES + rl * SB + cb * 16) = v;
+    }
+  };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
   // NS_GEMM_COLSUM_A: the workgroups of the first column tile also sum the A columns over the reduction (the bias
   // gradient of a conv: column sums of d(pre), which used to be a separate pass over the same bytes): the transposed
@@ -148,17 +179,24 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_tn_kernel(const ns_gemm_desc p
   };
 
   if (nsteps > 0) {
-    load(0);
-    store(0);
-    __syncthreads();
+    load(0, R[0]);
+    if (nsteps > 1) load(1, R[1]);
+    if (nsteps > 2) load(2, R[2]);
+    store(0, R[0], 0);
+    barrier();
     int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      const bool more = s + 1 < nsteps;
-      if (more) load(s + 1);
-      compute(cur);
-      if (more) store(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
+    for (int s = 0; s < nsteps; s += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = s + u;
+        if (t < nsteps) {                                   // (block-uniform)
+          if (t + 3 < nsteps) load(t + 3, R[u]);            // R[u] held step t: in LDS since the previous sub-step
+          compute(cur);
+          if (t + 1 < nsteps) store(cur ^ 1, R[(u + 1) % 3], t + 1);
+          barrier();
+          cur ^= 1;
+        }
+      }
     }
   }
 

@@ -279,3 +279,21 @@ def test_decode_self_attention_loads_are_branch_free_and_counted(tmp_path):
     assert best >= 8, f"only {best} row loads issued without a branch between them"
     waits = [o for o in ops[end + 1:] if o[0] == "s_waitcnt" and "vmcnt" in " ".join(o)]
     assert waits and "vmcnt(0)" not in " ".join(waits[0]), waits[:1]
+
+
+@pytest.mark.parametrize("variant,per_stage", [("ILi32ELi128ELb1E", 5), ("ILi128ELi32ELb0E", 5), ("ILi128ELi128ELb1E", 8)])
+def test_weight_gradient_gemm_keeps_two_stages_in_flight_behind_every_lds_store(tmp_path, variant, per_stage):
+    """ns_gemm_tn_kernel (LoRA dA / dB, the small conv gradients): three register stages of operand loads, issued as inline assembly in
+    program order; the store of a stage waits with vmcnt(2 x loads per stage) in the steady state (vmcnt(loads per stage) / vmcnt(0) on
+    the last two steps), the step barrier is a bare s_barrier, and hipcc's own (degenerate: vmcnt(0) behind this control flow) vector-memory
+    waits do not appear between the first load and the output atomics."""
+    ks = {k: v for k, v in _kernels(_asm("ns_gemm_tn.hip", tmp_path)).items() if "ns_gemm_tn_kernel" + variant in k}
+    assert len(ks) == 1, list(ks)
+    body = next(iter(ks.values()))
+    text = "\n".join(body)
+    assert not re.search(r"scratch_(load|store)", text)
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
+    assert waits.count(str(2 * per_stage)) >= 4 and waits.count(str(per_stage)) >= 4, waits      # prologue + the three sub-steps
+    assert set(waits) <= {"0", str(per_stage), str(2 * per_stage)}, waits
+    loads = len(re.findall(r"global_load_dwordx4", text))
+    assert loads == 6 * per_stage, loads                 # three prologue stages + one stage per sub-step of the loop unrolled by three
