@@ -37,6 +37,7 @@ from .ops import (NS_GEMM_ATOMIC32, NS_GEMM_COLSUM_A, NS_GEMM_DROP_A, NS_GEMM_GE
 # Every GELU site saves gelu'(x) (fp16) where the reference keeps x for autograd: the backward seams then multiply
 # (NS_GEMM_MUL_P16 / ns_dgelu_mul(pre_is_grad)) instead of re-evaluating erf / exp for every element.
 GELU_FWD = NS_GEMM_GELU | NS_GEMM_GELU_SAVE_GRAD
+_TN_TARGET = int(os.environ.get("NS_TN_TARGET", 768))     # workgroups a split weight-gradient launch aims at (A/B runs)
 from .weights import LORA_SUFFIXES, WhisperDims
 
 F16, F32 = torch.float16, torch.float32
@@ -670,7 +671,7 @@ class MegWhisperEngine:
         tiles = ((No + 127) // 128) * ((Ko + 127) // 128)
         # blocks in flight: ~1.5 per CU for the 128 x 32 tiles of dB (more splits only add atomics: 23 us at 384 blocks,
         # 30 us at 768 for N = 512), ~3 per CU for the others (tools/probe/tn_splits.py)
-        target = 384 if (Ko <= 96 or 32 < No <= 128) else 768
+        target = 384 if (Ko <= 96 or 32 < No <= 128) else _TN_TARGET
         # (short reductions -- the decoder's adapters under --ft_full, 2816 rows -- split down to one 64-row step per workgroup:
         # with 256-row ranges a 32 x 512 gradient ran on 44 workgroups of four dependent steps each, 29 us)
         splits = max(1, min(Mred // (256 if Mred >= 16384 else 64), (target + tiles - 1) // tiles))
