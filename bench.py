@@ -228,12 +228,13 @@ def eval_tokens_per_s(dev):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        return best, o.shape[1] - 4
+        return best, o.shape[1] - 4, gen.last_loop_mode
 
     for name, nb, kw in (("greedy", 1, {}), ("beam5_rep5_ngram2", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
-        t64, n64 = run(nb, kw, NEW)
-        t32, n32 = run(nb, kw, NEW // 2)
+        t64, n64, mode = run(nb, kw, NEW)
+        t32, n32, _ = run(nb, kw, NEW // 2)
         out[name] = round(B * n64 / t64, 1)
+        out.setdefault("loop_mode", {})[name] = mode      # "lists", or "lists->graphs@<step>" where the host turned out to be the bottleneck
         ms_step = (t64 - t32) / max(n64 - n32, 1) * 1e3
         t_mid = 4 + (n32 + n64) // 2                       # mean cache length over the differenced steps
         by = decode_bytes_per_step(dims, B, nb, t_mid)

@@ -15,6 +15,7 @@ Design notes (MI355X-first):
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -75,6 +76,10 @@ class Generator:
         self.graph_min_steps = int(os.environ.get("NS_GRAPH_MIN_STEPS", 128)) if graph_min_steps is None else graph_min_steps
         self.split_graph_min_steps = int(os.environ.get("NS_SPLIT_GRAPH_MIN_STEPS", 16))
         self.use_lists = os.environ.get("NS_LAUNCH_LISTS", "1") != "0"      # recorded launch lists for generations too short for graphs
+        self.adaptive = os.environ.get("NS_DECODE_ADAPT", "1") != "0"       # lists -> hipGraphs when the replays turn out host-bound
+        self.adaptive_min_steps = int(os.environ.get("NS_DECODE_ADAPT_MIN_STEPS", 24))
+        self.adaptive_frac = 0.8      # share of a chunk's wall time spent inside the replays that counts as host-bound
+        self.last_loop_mode = None
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
@@ -279,11 +284,54 @@ class Generator:
             n_sel = 0
             ctr = None
             graphs = None
+            is_list = False
+            self.last_loop_mode = "eager"
+            # host-bound watch (launch lists only): time spent inside the replays of a check_every-step chunk against the chunk's
+            # wall time (the flag poll at its end synchronizes anyway)
+            enq, chunk_t0, chunk_steps, slow_chunks = 0.0, None, 0, 0
+
+            def feed():
+                step(next_tok, cur, parent, ctr)
+                ops.add_i32(ctr, 1, n=2)
+
+            def build(as_list):
+                """the two (select, feed) pairs -- one per ping-pong parity -- as launch lists or as hipGraphs.  Nothing is launched;
+                the host-side lists end in the orientation they started in (two reversals)."""
+                pairs = []
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    if as_list:
+                        gs, gt = ops.LaunchList(), ops.LaunchList()
+                        with ops.recording(gs):
+                            select(cur, ctr)
+                        with ops.recording(gt):
+                            feed()
+                    else:
+                        gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                        # thread-local capture mode + the package's capture lock: other host threads (the data feed's
+                        # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
+                        with GPU_CAPTURE_LOCK:
+                            with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                                select(cur, ctr)
+                            with torch.cuda.graph(gt, capture_error_mode="thread_local"):
+                                feed()
+                    pairs.append((gs, gt))
+                return pairs
+
+            def replay(g):
+                nonlocal enq
+                if is_list:
+                    t0 = time.perf_counter()
+                    g.replay()
+                    enq += time.perf_counter() - t0
+                else:
+                    g.replay()
+
             while cur < max_len:
                 if graphs is None:
                     select(cur, None)
                 else:
-                    graphs[(n_sel - 1) & 1][0].replay()
+                    replay(graphs[(n_sel - 1) & 1][0])
                 n_sel += 1
                 cur += 1
                 if cur >= max_len:
@@ -292,6 +340,19 @@ class Generator:
                     f = flags.tolist()
                     if f[0] == 0 or (nb > 1 and f[1] == 0):
                         break
+                    if is_list:
+                        # Launch lists save the descriptor building, not the runtime's own launch path: on a slow host the replay of
+                        # ~72 launches still takes longer than the 0.86 ms the GPU needs for them (driver boxes of round 5: 1.00 ms per
+                        # greedy step, 99 k tokens/s against 105-106 k).  Two chunks in a row in which the host spent > 80 % of the wall
+                        # time inside the replays = host-bound: capture the hipGraphs after all (~3 ms, paid back within ~20 steps)
+                        now = time.perf_counter()
+                        if chunk_t0 is not None and chunk_steps == check_every:
+                            slow_chunks = slow_chunks + 1 if enq > self.adaptive_frac * (now - chunk_t0) else 0
+                            if slow_chunks >= 2 and graph_ok and self.adaptive and max_len - cur >= self.adaptive_min_steps:
+                                graphs = build(False)
+                                is_list = False
+                                self.last_loop_mode = f"lists->graphs@{cur - P}"
+                        enq, chunk_t0, chunk_steps = 0.0, time.perf_counter(), 0
                 if graphs is None:
                     step(next_tok, cur - 1, parent)
                     # two chains per step double the launches the host has to enqueue (~150 per step against ~0.6 ms of GPU time):
@@ -306,31 +367,12 @@ class Generator:
                     if as_graph or as_list:
                         # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
                         ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
-                        graphs = []
-                        torch.cuda.synchronize()
-
-                        def feed():
-                            step(next_tok, cur, parent, ctr)
-                            ops.add_i32(ctr, 1, n=2)
-                        for _ in range(2):
-                            if as_list:
-                                gs, gt = ops.LaunchList(), ops.LaunchList()
-                                with ops.recording(gs):
-                                    select(cur, ctr)
-                                with ops.recording(gt):
-                                    feed()
-                            else:
-                                gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                                # thread-local capture mode + the package's capture lock: other host threads (the data feed's
-                                # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
-                                with GPU_CAPTURE_LOCK:
-                                    with torch.cuda.graph(gs, capture_error_mode="thread_local"):
-                                        select(cur, ctr)
-                                    with torch.cuda.graph(gt, capture_error_mode="thread_local"):
-                                        feed()
-                            graphs.append((gs, gt))
+                        graphs = build(as_list)
+                        is_list = as_list
+                        self.last_loop_mode = "lists" if as_list else "graphs"
                 else:
-                    graphs[(n_sel - 2) & 1][1].replay()
+                    replay(graphs[(n_sel - 2) & 1][1])
+                    chunk_steps += 1
             if graphs is not None and (n_sel - 1) & 1:
                 for pair in ping_pong:      # replays do not touch the host-side lists: re-apply the odd reversal
                     pair.reverse()

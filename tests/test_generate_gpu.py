@@ -158,6 +158,35 @@ def test_split_decode_chains_give_the_same_ids(setup, monkeypatch, nb, kw):
         assert g2.last_split == split and torch.equal(out, ref), (split, graph)
 
 
+@pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
+def test_launch_lists_hand_over_to_graphs_when_the_host_is_the_bottleneck(setup, nb, kw):
+    """A generation too short for graphs replays launch lists; when two polled chunks in a row spend most of their wall time
+    inside the replays (a slow host: the runtime's own launch path, ~72 launches per step), the loop captures the hipGraphs
+    after all, mid-generation, from the device-resident counters.  Forced here (threshold 0): the switch happens, the ids are
+    those of the lists-only and of the eager loop, bit for bit; with the default threshold a GPU-bound... or host-bound run
+    must still give the same ids, whichever mode it ends in."""
+    from neuspeech1_amd.generate import Generator
+    g, dims, gen, x, prompt = setup
+    kw = dict(kw, suppress_tokens=(dims.eos_id,))      # every row runs the full length
+    eager = Generator(gen.eng, use_graph=False)
+    eager.use_lists = False
+    ref = eager.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
+    assert eager.last_loop_mode == "eager"
+    g2 = Generator(gen.eng, use_graph=True)          # graph_min_steps 128 > 60: lists
+    g2.adaptive = False
+    out = g2.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
+    assert g2.last_loop_mode == "lists" and torch.equal(out, ref)
+    g3 = Generator(gen.eng, use_graph=True)
+    g3.adaptive_frac = 0.0
+    out = g3.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
+    assert g3.last_loop_mode.startswith("lists->graphs@"), g3.last_loop_mode
+    assert torch.equal(out, ref)
+    g4 = Generator(gen.eng, use_graph=True)
+    out = g4.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
+    assert g4.last_loop_mode == "lists" or g4.last_loop_mode.startswith("lists->graphs@")
+    assert torch.equal(out, ref)
+
+
 def test_processors_and_topk_kernels(dev):
     """ns_logits_process / ns_topk_groups against torch on hand-built cases (G5 of SURVEY.md §8c)."""
     from neuspeech1_amd import ops

@@ -60,4 +60,4 @@ for nb, kw in ((1, dict(SB)), (5, dict(repetition_penalty=5.0, no_repeat_ngram_s
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     n = B * (out.shape[1] - 4)
-    print(f"beams={nb}: {n} tokens in {dt * 1e3:.1f} ms -> {n / dt:.0f} tokens/s ({dt / (out.shape[1] - 4) * 1e3:.2f} ms/step incl. encoder)", flush=True)
+    print(f"beams={nb}: {n} tokens in {dt * 1e3:.1f} ms -> {n / dt:.0f} tokens/s ({dt / (out.shape[1] - 4) * 1e3:.2f} ms/step incl. encoder; loop: {gen.last_loop_mode})", flush=True)
