@@ -78,7 +78,10 @@ class Generator:
         self.use_lists = os.environ.get("NS_LAUNCH_LISTS", "1") != "0"      # recorded launch lists for generations too short for graphs
         self.adaptive = os.environ.get("NS_DECODE_ADAPT", "1") != "0"       # lists -> hipGraphs when the replays turn out host-bound
         self.adaptive_min_steps = int(os.environ.get("NS_DECODE_ADAPT_MIN_STEPS", 24))
-        self.adaptive_frac = 0.8      # share of a chunk's wall time spent inside the replays that counts as host-bound
+        # share of a chunk's wall time spent inside the replays that counts as host-bound.  (0.8 fired on a fast host slowed by 8 us per
+        # launch -- 0.72 ms of replays inside 0.86 ms of GPU time: still GPU-bound, and the capture cost 2.2 ms of a 77-ms generation:
+        # tools/probe/decode_slow_host.py)
+        self.adaptive_frac = 0.95
         self.last_loop_mode = None
 
     @torch.no_grad()
@@ -343,7 +346,7 @@ class Generator:
                     if is_list:
                         # Launch lists save the descriptor building, not the runtime's own launch path: on a slow host the replay of
                         # ~72 launches still takes longer than the 0.86 ms the GPU needs for them (driver boxes of round 5: 1.00 ms per
-                        # greedy step, 99 k tokens/s against 105-106 k).  Two chunks in a row in which the host spent > 80 % of the wall
+                        # greedy step, 99 k tokens/s against 105-106 k).  Two chunks in a row in which the host spent > 95 % of the wall
                         # time inside the replays = host-bound: capture the hipGraphs after all (~3 ms, paid back within ~20 steps)
                         now = time.perf_counter()
                         if chunk_t0 is not None and chunk_steps == check_every:
