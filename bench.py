@@ -221,8 +221,8 @@ def eval_tokens_per_s(dev):
 
     def run(nb, kw, new):
         best = None
-        for _ in range(2):
-            torch.cuda.synchronize()
+        for _ in range(3):      # (an evaluation run calls generate() once per batch with one signature: the third call is its steady state --
+            torch.cuda.synchronize()   # the first records launch lists, the second captures the session's hipGraphs, later ones replay them)
             t0 = time.perf_counter()
             o = gen.generate(x, prompt, num_beams=nb, max_new_tokens=new, suppress_tokens=[dims.eos_id], check_every=8, **kw)
             torch.cuda.synchronize()

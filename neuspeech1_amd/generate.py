@@ -14,6 +14,7 @@ Design notes (MI355X-first):
 """
 from __future__ import annotations
 
+import collections
 import os
 import time
 
@@ -83,6 +84,29 @@ class Generator:
         # tools/probe/decode_slow_host.py)
         self.adaptive_frac = 0.95
         self.last_loop_mode = None
+        # decode SESSIONS: the device state of a generation (caches, score tables, token buffers, cross K/V) and the recorded launch
+        # lists / captured hipGraphs of its loop, kept per call signature: an evaluation run calls generate() with the same shapes and
+        # processors for every batch, and from the second call on nothing is allocated, recorded or captured again (the first call of
+        # a signature replays launch lists, the second captures the graphs, every later one replays them from the first step)
+        self.cache_sessions = os.environ.get("NS_DECODE_SESSIONS", "1") != "0"
+        self.max_sessions = 2
+        self._sessions = collections.OrderedDict()
+
+    def clear_sessions(self):
+        """release the device state, launch lists and hipGraphs kept for the call signatures seen so far"""
+        self._sessions.clear()
+
+    def _weights_fingerprint(self):
+        """device addresses of everything a recorded decoder launch points at: a reloaded / re-merged engine gets new sessions"""
+        eng = self.eng
+        ptrs = [eng.E16.data_ptr(), eng.E32.data_ptr(), eng.dec_pos.data_ptr()] + [t.data_ptr() for t in eng.dec_ln]
+        for Lw in eng.dec:
+            for v in Lw.values():
+                if isinstance(v, tuple):
+                    ptrs += [t.data_ptr() for t in v if torch.is_tensor(t)]
+                elif hasattr(v, "w"):
+                    ptrs += [v.w.data_ptr(), v.bias.data_ptr() if v.bias is not None else 0]
+        return hash(tuple(ptrs))
 
     @torch.no_grad()
     def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
@@ -108,6 +132,36 @@ class Generator:
         nb = num_beams
         Bp = B * nb
         max_len = min(P + max_new_tokens, dims.tgt_pos)
+        fewq = self.cross_mfma and 1 < nb <= 16
+        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or 1
+        nsplit = max(1, min(nsplit, B))
+        fused_select = dims.vocab_pad <= ops.SELECT_MAX_LDV and os.environ.get("NS_NO_FUSED_SELECT") != "1"
+        # ---- the session of this call signature (everything a recorded / captured launch has baked into it)
+        key = None
+        if self.cache_sessions and trace is None and dev.type == "cuda":
+            key = (B, P, nb, max_len, nsplit, fewq, fused_select, float(repetition_penalty), int(no_repeat_ngram_size),
+                   tuple(int(t) for t in suppress_tokens), tuple(int(t) for t in begin_suppress_tokens), float(length_penalty), eos, pad,
+                   repr(forced_decoder_ids), begin_index, repr(sequence_bias), str(dev), torch.cuda.current_stream().cuda_stream,
+                   self._weights_fingerprint())
+        ws = self._sessions.get(key) if key is not None else None
+        if ws is None:
+            ws = {"t": {}, "graphs": None, "lists": None, "calls": 0}
+            if key is not None:
+                self._sessions[key] = ws
+                while len(self._sessions) > self.max_sessions:
+                    self._sessions.popitem(last=False)
+        elif key is not None:
+            self._sessions.move_to_end(key)
+        first_call = ws["calls"] == 0
+
+        def T(name, make, init=None):
+            """a tensor of the session: made by the first call of the signature, re-initialised by `init` on every later one"""
+            t = ws["t"].get(name)
+            if t is None:
+                t = ws["t"][name] = make()
+            elif init is not None:
+                init(t)
+            return t
         # ---- encoder + per-sequence cross K/V
         eng.training_mode = False
         eng._cur_seed = 0
@@ -120,36 +174,38 @@ class Generator:
         # beams of a sequence = the few query rows of ns_attn_fewq (75 k tokens/s at beam 5, B = 128, against 71 k with
         # the 128-row flash kernel and 64 k with the per-key VALU kernel); the single greedy row stays on
         # ns_attn_decode (same speed, no transposed copy)
-        fewq = self.cross_mfma and 1 < nb <= 16
-        for Lw in eng.dec:
-            t = torch.empty(M, 2 * d, device=dev, dtype=F16)
+        for li, Lw in enumerate(eng.dec):
+            t = T(f"kvx{li}", lambda: torch.empty(M, 2 * d, device=dev, dtype=F16))
             eng._lin(enc16, M, Lw["ckv"], C16=t)
             kvx.append(t)
             if fewq:
                 # the cross V of a sequence is written once and read at every step: keep it transposed so the value
                 # product's MFMA operand is one 16-B load per lane (ns_attn_fewq)
-                vt = torch.empty(B, H, 64, Sp, device=dev, dtype=F16)
+                vt = T(f"vtx{li}", lambda: ops.zeros(B, H, 64, Sp, device=dev, dtype=F16))    # (columns [S, Sp) stay zero)
                 ops.vt_pack((t, d), 2 * d, vt, B, H, S, Sp)
                 vtx.append(vt)
         # ---- decode state
         nl = dims.dec_layers
-        kvc = [torch.zeros(max_len * Bp, 2 * d, device=dev, dtype=F16) for _ in range(nl)]
-        anc = [torch.zeros(Bp, max_len, device=dev, dtype=torch.int32) for _ in range(2)]
-        if nb == 1:     # greedy rows never change slots: the ancestry table is the identity, written once (no ns_anc_update per step)
+        # (a reused cache needs no clearing: a step reads positions below its own length only, all of them written by this generation;
+        # the ancestry table of step t is rebuilt from its first t entries)
+        kvc = [T(f"kvc{i}", lambda: torch.zeros(max_len * Bp, 2 * d, device=dev, dtype=F16)) for i in range(nl)]
+        anc = [T(f"anc{i}", lambda: torch.zeros(Bp, max_len, device=dev, dtype=torch.int32)) for i in range(2)]
+        if nb == 1 and first_call:     # greedy rows never change slots: the ancestry table is the identity, written once (no ns_anc_update per step)
             for a_ in anc:
                 a_.copy_(torch.arange(Bp, device=dev, dtype=torch.int32).unsqueeze(1).expand(Bp, max_len))
-        h = [torch.empty(Bp, d, device=dev, dtype=F32) for _ in range(2)]
-        x16 = torch.empty(Bp, d, device=dev, dtype=F16)
-        qkv = torch.empty(Bp, 3 * d, device=dev, dtype=F16)
-        qc = torch.empty(Bp, d, device=dev, dtype=F16)
-        ao = torch.empty(Bp, d, device=dev, dtype=F16)
-        gf = torch.empty(Bp, dims.ffn, device=dev, dtype=F16)
-        st = (torch.empty(Bp, device=dev), torch.empty(Bp, device=dev))
-        logits = torch.empty(Bp, Vp, device=dev, dtype=F16)
-        sb = _sequence_bias_tables(sequence_bias, V, dev)   # HF SequenceBiasLogitsProcessor (model.generate(sequence_bias=...))
+        h = [T(f"h{i}", lambda: torch.empty(Bp, d, device=dev, dtype=F32)) for i in range(2)]
+        x16 = T("x16", lambda: torch.empty(Bp, d, device=dev, dtype=F16))
+        qkv = T("qkv", lambda: torch.empty(Bp, 3 * d, device=dev, dtype=F16))
+        qc = T("qc", lambda: torch.empty(Bp, d, device=dev, dtype=F16))
+        ao = T("ao", lambda: torch.empty(Bp, d, device=dev, dtype=F16))
+        gf = T("gf", lambda: torch.empty(Bp, dims.ffn, device=dev, dtype=F16))
+        st = (T("st0", lambda: torch.empty(Bp, device=dev)), T("st1", lambda: torch.empty(Bp, device=dev)))
+        logits = T("logits", lambda: torch.empty(Bp, Vp, device=dev, dtype=F16))
+        if "sb" not in ws:
+            ws["sb"] = _sequence_bias_tables(sequence_bias, V, dev)   # HF SequenceBiasLogitsProcessor (model.generate(sequence_bias=...))
+        sb = ws["sb"]
         # processors + per-row top-k in one pass, no fp32 score matrix (a sequence bias takes the two-kernel form)
-        fused_select = Vp <= ops.SELECT_MAX_LDV and os.environ.get("NS_NO_FUSED_SELECT") != "1"
-        scores = None if fused_select else torch.empty(Bp, V, device=dev, dtype=F32)
+        scores = None if fused_select else T("scores", lambda: torch.empty(Bp, V, device=dev, dtype=F32))
 
         # Row ranges of the batch as independent chains on separate streams: a decode step is a serial chain in
         # which the HBM-bound cross-attention (393 MB per layer at B = 128, ~5.5 TB/s) and the latency-bound small-M projections /
@@ -163,8 +219,6 @@ class Generator:
         # chain costs as many launches whatever its row count, so two chains are twice the launches for the same dispatch rate,
         # and the cross-attention stream, already at 5.5 TB/s, has nothing to gain from sharing the pipe.  Launched eagerly two
         # chains are host-bound (55.5 k).  OFF by default; NS_DECODE_SPLIT=n turns it on.
-        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or 1
-        nsplit = max(1, min(nsplit, B))
         cuts = [B * k // nsplit for k in range(nsplit + 1)]
         side = [torch.cuda.Stream(dev) for _ in range(nsplit - 1)] if dev.type == "cuda" else []
         self.last_split = nsplit
@@ -245,8 +299,8 @@ class Generator:
             bad = [int(t) for t in lst if not 0 <= int(t) < V]
             if bad:     # these ids index the score row on the device
                 raise ValueError(f"The model vocabulary size is {V}, but `{name}` holds {bad}")
-        sup = torch.tensor(list(suppress_tokens), device=dev, dtype=torch.int32) if len(suppress_tokens) else None
-        bsup = torch.tensor(list(begin_suppress_tokens), device=dev, dtype=torch.int32) if len(begin_suppress_tokens) else None
+        sup = T("sup", lambda: torch.tensor(list(suppress_tokens), device=dev, dtype=torch.int32)) if len(suppress_tokens) else None
+        bsup = T("bsup", lambda: torch.tensor(list(begin_suppress_tokens), device=dev, dtype=torch.int32)) if len(begin_suppress_tokens) else None
         forced_tab, n_forced = None, 0
         if forced_decoder_ids:
             fmap = {int(i): t for i, t in forced_decoder_ids if t is not None}
@@ -259,7 +313,7 @@ class Generator:
                 for i, t in fmap.items():
                     if i >= 0:
                         tab[i] = int(t)
-                forced_tab = torch.tensor(tab, device=dev, dtype=torch.int32)
+                forced_tab = T("forced", lambda: torch.tensor(tab, device=dev, dtype=torch.int32))
         if forced_tab is not None:
             sb_forced = dict(forced=forced_tab, n_forced=n_forced)
         else:
@@ -270,12 +324,13 @@ class Generator:
                     suppress=sup, n_suppress=len(suppress_tokens), begin_suppress=bsup,
                     n_begin_suppress=len(begin_suppress_tokens), **sb)
 
-        seqs = [torch.full((Bp, max_len), pad, device=dev, dtype=torch.int64) for _ in range(2)]
+        seqs = [T(f"seqs{i}", lambda: torch.full((Bp, max_len), pad, device=dev, dtype=torch.int64), lambda t: t.fill_(pad)) for i in range(2)]
         seqs[0][:, :P] = prompt.repeat_interleave(nb, 0)
         for t in range(P):
             step(seqs[0][:, t].contiguous(), t, None)
-        flags = torch.zeros(2, device=dev, dtype=torch.int32)
-        next_tok = torch.empty(Bp, device=dev, dtype=torch.int64)
+        flags = T("flags", lambda: torch.zeros(2, device=dev, dtype=torch.int32), lambda t: t.zero_())
+        next_tok = T("next_tok", lambda: torch.empty(Bp, device=dev, dtype=torch.int64))
+        ctr_dev = T("ctr", lambda: torch.zeros(2, device=dev, dtype=torch.int32))
         cur = P
 
         graph_ok = self.use_graph and dev.type == "cuda" and trace is None
@@ -355,6 +410,8 @@ class Generator:
                                 graphs = build(False)
                                 is_list = False
                                 self.last_loop_mode = f"lists->graphs@{cur - P}"
+                                if key is not None:
+                                    ws["graphs"] = graphs
                         enq, chunk_t0, chunk_steps = 0.0, time.perf_counter(), 0
                 if graphs is None:
                     step(next_tok, cur - 1, parent)
@@ -367,12 +424,31 @@ class Generator:
                     # descriptors through ctypes costs the host 0.8-1.0 ms per step against 0.84 ms of GPU time -- the driver's
                     # 64-token eval leg ran host-bound on a slow host (100 k tokens/s against 108 k) -- and ~0.1 ms replayed.
                     as_list = not as_graph and self.use_lists and nsplit == 1 and trace is None and max_len - cur >= 4
-                    if as_graph or as_list:
+                    # A session that is called again (an evaluation loop: the same signature for every batch) replays what it holds --
+                    # the hipGraphs, captured by the SECOND call of the signature whatever the generation's length, or the lists
+                    if ws["graphs"] is None and graph_ok and key is not None and not first_call and max_len - cur >= 4:
+                        as_graph = True
+                    cached_graphs = ws["graphs"] is not None and graph_ok
+                    if as_graph or as_list or cached_graphs:
                         # counters as of the NEXT iteration: it selects token `cur` and feeds it at position `cur`
-                        ctr = torch.tensor([cur, cur + 1], device=dev, dtype=torch.int32)
-                        graphs = build(as_list)
-                        is_list = as_list
-                        self.last_loop_mode = "lists" if as_list else "graphs"
+                        ctr = ctr_dev
+                        ctr.copy_(torch.tensor([cur, cur + 1], dtype=torch.int32))
+                        if cached_graphs:
+                            graphs, is_list = ws["graphs"], False
+                            self.last_loop_mode = "graphs (session)"
+                        elif as_graph:
+                            graphs, is_list = build(False), False
+                            self.last_loop_mode = "graphs"
+                            if key is not None:
+                                ws["graphs"] = graphs
+                        elif ws["lists"] is not None and as_list:
+                            graphs, is_list = ws["lists"], True
+                            self.last_loop_mode = "lists (session)"
+                        else:
+                            graphs, is_list = build(True), True
+                            self.last_loop_mode = "lists"
+                            if key is not None:
+                                ws["lists"] = graphs
                 else:
                     replay(graphs[(n_sel - 2) & 1][1])
                     chunk_steps += 1
@@ -381,11 +457,11 @@ class Generator:
                     pair.reverse()
 
         if nb == 1:
-            done = torch.zeros(Bp, device=dev, dtype=torch.uint8)
+            done = T("done", lambda: torch.zeros(Bp, device=dev, dtype=torch.uint8), lambda t: t.zero_())
             parent = None
 
-            cand_v = torch.empty(Bp, device=dev, dtype=F32)
-            cand_i = torch.empty(Bp, device=dev, dtype=torch.int32)
+            cand_v = T("cand_v", lambda: torch.empty(Bp, device=dev, dtype=F32))
+            cand_i = T("cand_i", lambda: torch.empty(Bp, device=dev, dtype=torch.int32))
 
             if trace is not None and not fused_select:
                 raise ValueError("trace needs the fused selection kernel (vocabulary within SELECT_MAX_LDV, no NS_NO_FUSED_SELECT)")
@@ -410,19 +486,19 @@ class Generator:
             run_loop(select, [])
             out = seqs[0]
         else:
-            run_scores = [torch.zeros(B, nb, device=dev, dtype=F32) for _ in range(2)]
+            run_scores = [T(f"run_scores{i}", lambda: torch.zeros(B, nb, device=dev, dtype=F32), lambda t: t.zero_()) for i in range(2)]
             run_scores[0][:, 1:] = -1e9
-            fin_seqs = [seqs[0].clone(), seqs[0].clone()]
-            fin_scores = [torch.full((B, nb), -1e9, device=dev, dtype=F32) for _ in range(2)]
-            fin_done = [torch.zeros(B, nb, device=dev, dtype=torch.uint8) for _ in range(2)]
-            open_row = torch.ones(B, device=dev, dtype=torch.uint8)
-            top_v = torch.empty(B, 2 * nb, device=dev, dtype=F32)
-            top_i = torch.empty(B, 2 * nb, device=dev, dtype=torch.int32)
-            parent = torch.empty(Bp, device=dev, dtype=torch.int32)
+            fin_seqs = [T(f"fin_seqs{i}", lambda: seqs[0].clone(), lambda t: t.copy_(seqs[0])) for i in range(2)]
+            fin_scores = [T(f"fin_scores{i}", lambda: torch.full((B, nb), -1e9, device=dev, dtype=F32), lambda t: t.fill_(-1e9)) for i in range(2)]
+            fin_done = [T(f"fin_done{i}", lambda: torch.zeros(B, nb, device=dev, dtype=torch.uint8), lambda t: t.zero_()) for i in range(2)]
+            open_row = T("open_row", lambda: torch.ones(B, device=dev, dtype=torch.uint8), lambda t: t.fill_(1))
+            top_v = T("top_v", lambda: torch.empty(B, 2 * nb, device=dev, dtype=F32))
+            top_i = T("top_i", lambda: torch.empty(B, 2 * nb, device=dev, dtype=torch.int32))
+            parent = T("parent", lambda: torch.empty(Bp, device=dev, dtype=torch.int32))
             pairs = [seqs, run_scores, fin_seqs, fin_scores, fin_done]
 
-            cand_v = torch.empty(Bp, 2 * nb, device=dev, dtype=F32)
-            cand_i = torch.empty(Bp, 2 * nb, device=dev, dtype=torch.int32)
+            cand_v = T("cand_v", lambda: torch.empty(Bp, 2 * nb, device=dev, dtype=F32))
+            cand_i = T("cand_i", lambda: torch.empty(Bp, 2 * nb, device=dev, dtype=torch.int32))
 
             def select(c, ctr):
                 if fused_select:
@@ -453,4 +529,5 @@ class Generator:
         first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((o.shape[0],), gen.shape[1]))
         width = P + int(first.max().item()) if gen.shape[1] > 0 else P
         width = min(width, cur)
-        return out[:, :width].contiguous()
+        ws["calls"] += 1
+        return out[:, :width].clone()       # (the session's buffers are written again by the next call)

@@ -187,6 +187,41 @@ def test_launch_lists_hand_over_to_graphs_when_the_host_is_the_bottleneck(setup,
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
+def test_decode_sessions_replay_across_calls(setup, dev, nb, kw):
+    """A Generator keeps the device state and the recorded / captured loop of a call signature (an evaluation run: one signature for
+    every batch): call 1 records launch lists, call 2 captures the hipGraphs, call 3 replays them from its first loop step -- on
+    OTHER inputs each time.  Every call must give the ids of a fresh generator on the same input, results handed out earlier must
+    not change when the session's buffers are written again, another signature gets its own session, and clear_sessions() starts over."""
+    from neuspeech1_amd.generate import Generator
+    g, dims, gen, x, prompt = setup
+    kw = dict(kw, suppress_tokens=(dims.eos_id,))
+    xs = [x, torch.roll(x, 1, 0) * 0.9, torch.flip(x, (2,))]
+    fresh = []
+    for xi in xs:
+        f = Generator(gen.eng, use_graph=False)
+        f.use_lists = False
+        f.cache_sessions = False
+        fresh.append(f.generate(xi, prompt, num_beams=nb, max_new_tokens=40, **kw))
+    g2 = Generator(gen.eng)
+    outs, modes = [], []
+    for xi in xs + [xs[0]]:
+        outs.append(g2.generate(xi, prompt, num_beams=nb, max_new_tokens=40, **kw))
+        modes.append(g2.last_loop_mode)
+    assert modes[0] == "lists" and modes[1] == "graphs" and modes[2] == modes[3] == "graphs (session)", modes
+    for o, ref in zip(outs, fresh + [fresh[0]]):
+        assert torch.equal(o, ref)
+    assert len(g2._sessions) == 1
+    short = g2.generate(xs[1], prompt, num_beams=nb, max_new_tokens=12, **kw)       # another signature
+    assert g2.last_loop_mode == "lists" and len(g2._sessions) == 2
+    f = Generator(gen.eng, use_graph=False)
+    f.cache_sessions = False
+    assert torch.equal(short, f.generate(xs[1], prompt, num_beams=nb, max_new_tokens=12, **kw))
+    assert torch.equal(outs[1], fresh[1])                                          # handed-out results are copies
+    g2.clear_sessions()
+    assert torch.equal(g2.generate(xs[2], prompt, num_beams=nb, max_new_tokens=40, **kw), fresh[2]) and g2.last_loop_mode == "lists"
+
+
 def test_processors_and_topk_kernels(dev):
     """ns_logits_process / ns_topk_groups against torch on hand-built cases (G5 of SURVEY.md §8c)."""
     from neuspeech1_amd import ops

@@ -53,7 +53,7 @@ if MARK:
 for nb, kw in ((1, dict(SB)), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2, **SB))):
     if ONLY and int(ONLY) != nb:
         continue
-    for it in range(2):
+    for it in range(3):     # the third call of a signature is the session's steady state (lists, then the capture, then replays)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = gen.generate(x, prompt, num_beams=nb, max_new_tokens=NEW, suppress_tokens=[dims.eos_id], check_every=8, **kw)

@@ -37,6 +37,7 @@ case "$mode" in
     python3 "$ROOT/tools/pmc_decode_summary.py" "$tag"
     ;;
   decode)
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/tools/bench_decode.py" "$@" > "$OUT/decode_$tag.log" 2> "$OUT/prof_$tag.log"
+    # (GRAPH=0: launch lists all the way -- a session's second call would capture hipGraphs, whose kernels the trace does not list)
+    GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o k -- python3 "$ROOT/tools/bench_decode.py" "$@" > "$OUT/decode_$tag.log" 2> "$OUT/prof_$tag.log"
     ;;
 esac

@@ -438,12 +438,17 @@ class WhisperForConditionalGeneration(nn.Module):
         if forced is None:
             forced = forced_decoder_ids
         begin_index = P + int(forced[-1][0]) if forced else P
-        return Generator(eng).generate(x, prompt, num_beams=num_beams, max_new_tokens=new,
-                                       repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
-                                       suppress_tokens=list(sup), begin_suppress_tokens=list(bsup),
-                                       length_penalty=length_penalty, eos_id=one(default("eos_token_id", eos_token_id)),
-                                       pad_id=one(default("pad_token_id", pad_token_id)), sequence_bias=sequence_bias,
-                                       forced_decoder_ids=forced, begin_index=begin_index)
+        # one Generator per engine: it keeps the decode sessions (device state + recorded launch lists / captured hipGraphs per call
+        # signature), so that the evaluation loop's second batch captures and every later one only replays (neuspeech1_amd/generate.py)
+        gen = getattr(self, "_generator", None)
+        if gen is None or gen.eng is not eng:
+            gen = self._generator = Generator(eng)
+        return gen.generate(x, prompt, num_beams=num_beams, max_new_tokens=new,
+                            repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
+                            suppress_tokens=list(sup), begin_suppress_tokens=list(bsup),
+                            length_penalty=length_penalty, eos_id=one(default("eos_token_id", eos_token_id)),
+                            pad_id=one(default("pad_token_id", pad_token_id)), sequence_bias=sequence_bias,
+                            forced_decoder_ids=forced, begin_index=begin_index)
 
 
 def _resolve_device(device_map):
