@@ -525,7 +525,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     const bool big = g_use_ring == 3 || g_use_ring == 4 || g_use_ring == 9 ||
                      ((g_use_ring == 1 || g_use_ring == 5) && d->N >= 256 && tiles256 >= 192 &&
-                      (d->M >= 2048 || (d->M >= 512 && d->N >= 8192)));      // (M >= 512 with a very wide N: the LM head of a beam-search step, 640 x 51 968: 58 us against 67 on the 128^2 ring)
+                      (d->M >= 2048 || (d->M >= 128 && d->N >= 8192)));      // (few rows with a very wide N: the LM head of a decode step, 51 968 columns -- 640 rows: 59 us against 89 on the 128^2 ring, 128 rows: 19.1 against 23.8, 256 rows: 21.5 against 44.8; tools/probe/head_gemm.py)
     const bool p8_ok = (!d->C32 || (d->flags & (1 << 27))) && d->N % 8 == 0 && (!d->C16 || d->c16m.ld % 8 == 0) &&
                        (!d->G16 || d->g16m.ld % 8 == 0) && (!d->P16 || d->p16m.ld % 8 == 0) &&
                        (!d->H32 || d->h32m.ld % 8 == 0) && ns_gemm_p8_fits(d);

@@ -134,7 +134,7 @@ def gemm(**kw):
     elif N <= 96 or (M <= 1024 and N <= 4096):
         kind = "nt32"
     else:   # mirrors the dispatch in csrc/ns_gemm.hip
-        kind = "nt256" if (N >= 256 and (M >= 2048 or (M >= 512 and N >= 8192)) and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
+        kind = "nt256" if (N >= 256 and (M >= 2048 or (M >= 128 and N >= 8192)) and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
     _call("ns_gemm", C.byref(d))
