@@ -789,6 +789,21 @@ def test_attn_decode_cache_layout_with_ancestry(ops, dev, Lk, H, ad_self_form):
     k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
     ref2 = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).reshape(rows, H * d)
     close(O2, ref2, 2e-3, 2e-3, "attn_decode append")
+    # a ROW RANGE of the batch as its own launch (NS_DECODE_SPLIT's chains): Q / anc / O offset by the range, the cache at its base,
+    # slot0 = the range's first slot -- the rows of the range, and only those, are appended and attended
+    r0, r1 = 3, 8
+    cache3 = cache.clone()
+    cache3.view(Lmax, rows, 2 * H * d)[Lk - 1] = 777.0
+    O3 = torch.full_like(O, float("nan"))
+    ops.attn_decode(Q=Q[r0:r1], K=cache3, V=(cache3, H * d), O=O3[r0:r1], groups=r1 - r0, nq=1, H=H, Lk=Lmax, Lk_max=Lmax, ldq=3 * H * d,
+                    ldk=2 * H * d, ldv=2 * H * d, ldo=H * d, anc=anc2[r0:r1], anc_ld=Lmax, kv_pos_stride=rows, kv_len_dev=klen,
+                    Knew=(Q[r0:r1], H * d), Vnew=(Q[r0:r1], 2 * H * d), ldnew=3 * H * d, slot0=r0)
+    got = cache3.view(Lmax, rows, 2 * H * d)[Lk - 1]
+    assert torch.equal(got[r0:r1], Q[r0:r1, H * d:]) and bool((got[:r0] == 777.0).all()) and bool((got[r1:] == 777.0).all())
+    if Lk == 1 or bool((anc2[r0:r1, :Lk - 1] >= 0).all()):
+        # (older positions may point at slots outside the range: they read the cache as it is -- equal to `want` there)
+        assert torch.equal(O3[r0:r1], O2[r0:r1])
+    assert bool(torch.isnan(O3[:r0]).all()) and bool(torch.isnan(O3[r1:]).all())
 
 
 @pytest.mark.parametrize("nq,Lk", [(5, 1500), (1, 1500), (16, 97), (3, 31), (8, 128), (2, 1)])
