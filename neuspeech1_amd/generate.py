@@ -90,6 +90,7 @@ class Generator:
         # a signature replays launch lists, the second captures the graphs, every later one replays them from the first step)
         self.cache_sessions = os.environ.get("NS_DECODE_SESSIONS", "1") != "0"
         self.max_sessions = 2
+        self.max_session_frac = 0.25      # of the device memory, all sessions together (large-v2 at B = 128, beam 5: 62 GB of cross K|V images each)
         self._sessions = collections.OrderedDict()
 
     def clear_sessions(self):
@@ -530,4 +531,12 @@ class Generator:
         width = P + int(first.max().item()) if gen.shape[1] > 0 else P
         width = min(width, cur)
         ws["calls"] += 1
-        return out[:, :width].clone()       # (the session's buffers are written again by the next call)
+        res = out[:, :width].clone()       # (the session's buffers are written again by the next call)
+        if key is not None and dev.type == "cuda":
+            # sessions are a cache: together they may hold at most max_session_frac of the device memory (oldest out first; a single
+            # session above the cap is not kept at all)
+            cap = self.max_session_frac * torch.cuda.get_device_properties(dev).total_memory
+            size = lambda w: sum(t.numel() * t.element_size() for t in w["t"].values())       # noqa: E731
+            while self._sessions and sum(size(w) for w in self._sessions.values()) > cap:
+                self._sessions.popitem(last=False)
+        return res

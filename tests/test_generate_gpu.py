@@ -204,6 +204,7 @@ def test_decode_sessions_replay_across_calls(setup, dev, nb, kw):
         f.cache_sessions = False
         fresh.append(f.generate(xi, prompt, num_beams=nb, max_new_tokens=40, **kw))
     g2 = Generator(gen.eng)
+    g2.adaptive = False        # (at these dims a replayed step is as long on the host as on the GPU: the hand-over would fire now and then)
     outs, modes = [], []
     for xi in xs + [xs[0]]:
         outs.append(g2.generate(xi, prompt, num_beams=nb, max_new_tokens=40, **kw))
@@ -220,6 +221,8 @@ def test_decode_sessions_replay_across_calls(setup, dev, nb, kw):
     assert torch.equal(outs[1], fresh[1])                                          # handed-out results are copies
     g2.clear_sessions()
     assert torch.equal(g2.generate(xs[2], prompt, num_beams=nb, max_new_tokens=40, **kw), fresh[2]) and g2.last_loop_mode == "lists"
+    g2.max_session_frac = 0.0                      # the memory cap: a session above it is dropped after its call
+    assert torch.equal(g2.generate(xs[0], prompt, num_beams=nb, max_new_tokens=40, **kw), fresh[0]) and len(g2._sessions) == 0
 
 
 def test_processors_and_topk_kernels(dev):
