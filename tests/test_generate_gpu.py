@@ -181,6 +181,8 @@ def test_launch_lists_hand_over_to_graphs_when_the_host_is_the_bottleneck(setup,
     out = g3.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
     assert g3.last_loop_mode.startswith("lists->graphs@"), g3.last_loop_mode
     assert torch.equal(out, ref)
+    out = g3.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)     # the graphs captured mid-generation serve the next call from its first step
+    assert g3.last_loop_mode == "graphs (session)" and torch.equal(out, ref)
     g4 = Generator(gen.eng, use_graph=True)
     out = g4.generate(x, prompt, num_beams=nb, max_new_tokens=60, **kw)
     assert g4.last_loop_mode == "lists" or g4.last_loop_mode.startswith("lists->graphs@")
