@@ -36,6 +36,117 @@ DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
 PMC_FILE = "profiles/r5_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
 DECODE_PMC_FILE = "profiles/r5_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
 LV2_GFLOP_PER_SAMPLE = 5630.0   # whisper-large-v2, 273-ch, fwd+bwd
+# round 6: the external yardstick (tools/probe/vendor_yardstick.py -> profiles/r6_yardstick.json): the MFMA rate and HBM rate this chip HOLDS.
+# `frac` stays against the spec peaks (2.5 PFLOP/s, 8 TB/s); `frac_of_sustained` is reported BESIDE it, never instead of it.
+YARDSTICK_FILE = "profiles/r6_yardstick.json"
+HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6300.0      # spec; float4 copy (MI355X_MICROARCH.md)
+SQ_FILE = "profiles/r5_pmc_SQ_by_kernel.tsv"
+
+
+def sustained_mfma_tflops():
+    """the fp16 MFMA rate the chip sustains on RANDOM operands held in registers, every CU busy for seconds (back-to-back
+    v_mfma_f32_16x16x32_f16, two waves per SIMD: the dominant GEMM's shape and occupancy), from the committed yardstick run; None without it"""
+    try:
+        d = json.load(open(os.path.join(ROOT, YARDSTICK_FILE)))
+        c = [r["tflops"] for r in d["mfma_clock"] if r["probe"] == "mfma_16x16x32_f16 regs random" and r["waves_per_simd"] == 2]
+        return round(sum(c) / len(c), 1) if c else None
+    except Exception:
+        return None
+
+
+# step_budget families: (family, class prefixes of ops.STEP_PROFILE, kernel-name fragments of the rocprof files)
+FAMILIES = [
+    ("gemm 256x256 (dominant)", ("gemm nt256",), ("ns_gemm_p8s_kernel", "ns_gemm_p8_kernel")),
+    ("gemm + LayerNorm rows", ("gemm rowln",), ("gemm_ln_kernel",)),
+    ("gemm 128x128 / 64x128 ring", ("gemm nt128",), ("ns_gemm_ring_kernel", "ns_gemm_ring256_kernel")),
+    ("gemm skinny / small", ("gemm nt32",), ("ns_gemm_skinny_kernel", "ns_gemm_kernel", "ns_gemm_smallm")),
+    ("weight gradients (TN)", ("gemm tn",), ("ns_gemm_tn_kernel", "ns_gemm_tn256_kernel")),
+    ("attention backward, one pass", ("attn_bwd one pass",), ("attn_bwd1_kernel",)),
+    ("attention forward", ("attn_fwd",), ("attn_fwd_kernel", "attn_fewq")),
+    ("attention backward, decoder", ("attn_bwd",), ("attn_bwd_fewq_kernel", "attn_fewq_dq_reduce_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel")),
+    ("LayerNorm backward", ("layernorm_bwd",), ("ln_bwd_kernel",)),
+    ("LayerNorm forward", ("layernorm_fwd",), ("ln_fwd_kernel",)),
+    ("adapter up-projection backward", ("lora_bwd_dudb",), ("lora_bwd_dudb_kernel", "lora_bwd_reduce_kernel")),
+    ("side-product reduce", ("side_reduce",), ("side_reduce_kernel",)),
+    ("loss", ("cross_entropy",), ("ce_kernel",)),
+    ("optimizer", ("adamw_step", "grad_norm", "cast_jobs"), ("adamw_kernel", "norm_partial_kernel", "norm_final", "cast_jobs_kernel")),
+    ("clears / packing / rest", ("",), ()),
+]
+
+
+def _counter_tables():
+    """per kernel: HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, PMC_FILE) and mfma_busy (SQ_FILE), both hash-guarded; {} when stale"""
+    traffic, busy, steps_in_file = {}, {}, None
+    try:
+        from tools.kernel_hash import DOMINANT_SOURCES, source_hash
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        if d.get("kernel_source_sha256_16") == source_hash(DOMINANT_SOURCES):
+            traffic = {k: (v["launches"], v["hbm_bytes_per_launch"]) for k, v in d["kernels"].items()}
+            steps_in_file = d.get("launches")
+    except Exception:
+        pass
+    try:
+        import csv
+        with open(os.path.join(ROOT, SQ_FILE)) as f:
+            for r in csv.DictReader(f, delimiter="\t"):
+                busy[r["kernel"]] = (float(r["launches"]), float(r["SQ_BUSY_CYCLES_per_launch"]), float(r["mfma_busy"]))
+    except Exception:
+        pass
+    return traffic, busy, steps_in_file
+
+
+def step_budget(recs, step_ms, sustained):
+    """one eager step, every launch bracketed by HIP events (ops.STEP_PROFILE).  Per class and per family: launches, time,
+    algorithmic FLOP and bytes, achieved rates, the floor max(bytes / HBM rate, FLOP / MFMA rate) at the spec peaks and at the sustained rates,
+    which of the two bounds it; per family also the fabric-side counter bytes and mfma_busy of the committed rocprofv3 passes."""
+    cls = {}
+    for c, fl, by, e0, e1 in recs:
+        a = cls.setdefault(c, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += fl
+        a[3] += by
+    sus_f = (sustained or MFMA_PEAK_TFLOPS) * 1e12
+
+    def row(n, ms, fl, by):
+        f_spec = max(by / (HBM_PEAK_GBS * 1e9), fl / (MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+        t_h, t_m = by / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3, fl / sus_f * 1e3
+        return {"launches": n, "ms": round(ms, 3), "gflop": round(fl / 1e9, 1), "algorithmic_gb": round(by / 1e9, 3),
+                "tflops": round(fl / max(ms, 1e-9) / 1e9, 1), "tb_per_s": round(by / max(ms, 1e-9) / 1e9, 2),
+                "floor_ms_spec": round(f_spec, 3), "floor_ms_sustained": round(max(t_h, t_m), 3), "bound": "hbm" if t_h >= t_m else "mfma"}
+    classes = {c: row(*a) for c, a in sorted(cls.items(), key=lambda kv: -kv[1][1])}
+    traffic, busy, dom_launches = _counter_tables()
+    fams, used = {}, set()
+    nt256_launches = sum(a[0] for c, a in cls.items() if c.startswith("gemm nt256"))
+    file_steps = (dom_launches / nt256_launches) if (dom_launches and nt256_launches) else None
+    for name, prefixes, frags in FAMILIES:
+        mine = [c for c in cls if c not in used and any(c.startswith(p) for p in prefixes)]
+        used.update(mine)
+        if not mine:
+            continue
+        n, ms, fl, by = (sum(cls[c][i] for c in mine) for i in range(4))
+        r = row(n, ms, fl, by)
+        if frags and traffic and file_steps:
+            tb = sum(v[0] * v[1] for k, v in traffic.items() if any(f in k for f in frags))
+            r["counter_gb"] = round(tb / file_steps / 1e9, 3)
+            r["counter_over_algorithmic"] = round(tb / file_steps / max(by, 1.0), 2)
+        if frags and busy:
+            w = [(v[0] * v[1], v[2]) for k, v in busy.items() if any(f in k for f in frags)]
+            if w and sum(x for x, _ in w) > 0:
+                r["mfma_busy"] = round(sum(x * b for x, b in w) / sum(x for x, _ in w), 3)
+        fams[name] = r
+    tot_ms = sum(a[1] for a in cls.values())
+    tot = row(sum(a[0] for a in cls.values()), tot_ms, sum(a[2] for a in cls.values()), sum(a[3] for a in cls.values()))
+    tot["floor_ms_spec"] = round(sum(v["floor_ms_spec"] for v in classes.values()), 3)             # SUM of the classes' floors: a step is a chain
+    tot["floor_ms_sustained"] = round(sum(v["floor_ms_sustained"] for v in classes.values()), 3)
+    tot.pop("bound")
+    if traffic and file_steps:
+        tot["counter_gb"] = round(sum(v[0] * v[1] for v in traffic.values()) / file_steps / 1e9, 2)
+    return {"source": "one eager step, HIP events around every entry-point launch (a replayed step has no gaps between them: step time = "
+                      "kernel time); algorithmic bytes = every operand and output once; counters from " + PMC_FILE + " / " + SQ_FILE,
+            "rates": {"hbm_spec_gb_s": HBM_PEAK_GBS, "hbm_achievable_gb_s": HBM_ACHIEVABLE_GBS, "mfma_spec_tflops": MFMA_PEAK_TFLOPS,
+                      "mfma_sustained_tflops": sustained},
+            "step_ms_replayed": round(step_ms, 3), "total": tot, "families": fams, "classes": classes}
 
 
 def cpu_baseline(dims, r, alpha):
@@ -58,7 +169,7 @@ def cpu_baseline(dims, r, alpha):
     for _ in range(n):
         O.loss_and_grads(sd, lora, x, labels, dims, alpha / r)
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(B * n / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle fp32 fwd+bwd, whisper-base {dims.ch}-ch, B={B}, {n} timed passes after 1 warm-up"}
 
 
@@ -118,7 +229,7 @@ def cpu_reference_object(dims, B=4):
         step()
     train = B * 3 / (time.perf_counter() - t0)
     model.eval()
-    out = {"value": round(train, 4), "unit": "samples/s", "cores": cores, "kind": "reference",
+    out = {"value": round(train, 4), "unit": "samples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "reference",
            "kind_detail": "reference object: stock transformers Whisper + the conv stack, i.e. what /root/reference/evaluation.py:72-86 "
                           "builds (the reference's own files cannot travel to the GPU box; peft is not in the image)",
            "unit_decode": "tokens/s",
@@ -220,20 +331,24 @@ def eval_tokens_per_s(dev):
            "roofline": {}}
 
     def run(nb, kw, new):
-        best = None
+        best = first = None
         for _ in range(3):      # (an evaluation run calls generate() once per batch with one signature: the third call is its steady state --
             torch.cuda.synchronize()   # the first records launch lists, the second captures the session's hipGraphs, later ones replay them)
             t0 = time.perf_counter()
             o = gen.generate(x, prompt, num_beams=nb, max_new_tokens=new, suppress_tokens=[dims.eos_id], check_every=8, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            first = dt if first is None else first
             best = dt if best is None else min(best, dt)
-        return best, o.shape[1] - 4, gen.last_loop_mode
+        return best, o.shape[1] - 4, gen.last_loop_mode, first
 
     for name, nb, kw in (("greedy", 1, {}), ("beam5_rep5_ngram2", 5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))):
-        t64, n64, mode = run(nb, kw, NEW)
-        t32, n32, _ = run(nb, kw, NEW // 2)
+        t64, n64, mode, first64 = run(nb, kw, NEW)
+        t32, n32, _, _ = run(nb, kw, NEW // 2)
         out[name] = round(B * n64 / t64, 1)
+        # the FIRST call of a signature (records the launch lists; nothing captured yet), beside the steady state `value` quotes
+        out.setdefault("first_call_ms", {})[name] = round(first64 * 1e3, 2)
+        out.setdefault("steady_call_ms", {})[name] = round(t64 * 1e3, 2)
         out.setdefault("loop_mode", {})[name] = mode      # "lists", or "lists->graphs@<step>" where the host turned out to be the bottleneck
         ms_step = (t64 - t32) / max(n64 - n32, 1) * 1e3
         t_mid = 4 + (n32 + n64) // 2                       # mean cache length over the differenced steps
@@ -387,7 +502,7 @@ def main():
         gstat["per_rank"] = [{"replays": int(f[0]), "capture_failures": int(f[1]), "captures": int(f[2])} for f in allf]
         gstat["timed_steps_replayed"] = all(int(f[0]) >= args.steps and int(f[1]) == 0 for f in allf)
 
-    roof = None
+    roof = budget = None
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the 256x256 LDS-DMA ring GEMM: one extra instrumented step, HIP events on the launch stream
         ops.GEMM_PROFILE = []
@@ -395,21 +510,34 @@ def main():
         torch.cuda.synchronize()
         recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         tot = {}
-        for kind, fl, e0, e1 in recs:
-            a = tot.setdefault(kind, [0.0, 0.0, 0])
+        for kind, fl, e0, e1, by in recs:
+            a = tot.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            a[3] += by
         dom = "nt256" if "nt256" in tot else "nt128"
-        fl, sec, n = tot[dom]
+        fl, sec, n, by = tot[dom]
         ach = fl / sec / 1e12
+        sustained = sustained_mfma_tflops()
+        traffic = _pmc_traffic(DOMINANT if dom == "nt256" else None)
         roof = {"bound": "mfma", "kernel": DOMINANT if dom == "nt256" else "ns_gemm_ring_kernel", "achieved": round(ach, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": _pmc_traffic(DOMINANT if dom == "nt256" else None), "traffic_source": PMC_FILE,
+                "sustained_peak": sustained, "frac_of_sustained": round(ach / sustained, 4) if sustained else None,
+                "sustained_source": YARDSTICK_FILE + " (back-to-back v_mfma_f32_16x16x32_f16 on random operands, every CU, seconds)",
+                "traffic": traffic, "traffic_source": PMC_FILE,
+                "algorithmic_bytes_per_launch": round(by / n),
+                "traffic_over_algorithmic": round(traffic / (by / n), 3) if traffic else None,
                 "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                 "gflop_per_launch": round(fl / n / 1e9, 2),
                 "step_share": {k: {"ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / max(v[1], 1e-12) / 1e12, 1),
                                    "launches": v[2]} for k, v in tot.items()}}
+        # the step's byte / FLOP budget by kernel class (one more instrumented eager step)
+        ops.STEP_PROFILE = []
+        eng.train_step(xd, ld)
+        torch.cuda.synchronize()
+        srecs, ops.STEP_PROFILE = ops.STEP_PROFILE, None
+        budget = step_budget(srecs, dt / args.steps * 1e3, sustained)
     # encoder-only forward + backward (the quantity north_star's 40 % MFMA target is stated on): HIP events on the
     # launch stream at the encoder's section boundaries, one extra local step on rank 0
     enc = None
@@ -423,6 +551,8 @@ def main():
         gfe = ENC_GFLOP_PER_SAMPLE.get(args.ch, ENC_GFLOP_PER_SAMPLE[208])
         enc = {"fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "algorithmic_gflop_per_sample": gfe,
                "mfma_frac": round(B * gfe * 1e9 / ((fwd_ms + bwd_ms) * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+        sus = sustained_mfma_tflops()
+        enc["mfma_frac_of_sustained"] = round(B * gfe * 1e9 / ((fwd_ms + bwd_ms) * 1e-3) / (sus * 1e12), 4) if sus else None
 
     dp = None
     if red is not None:
@@ -484,7 +614,7 @@ def main():
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
                        "train_step_graph": bool(gstat["timed_steps_replayed"]), "graph": gstat},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "torch_rocm_reference_object": gpu_ref,
-            "encoder_fwd_bwd": enc, "dp": dp, "eval": ev, "large_v2": lv2,
+            "encoder_fwd_bwd": enc, "dp": dp, "eval": ev, "large_v2": lv2, "step_budget": budget,
         }
         print(json.dumps(out), flush=True)
 

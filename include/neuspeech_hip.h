@@ -158,10 +158,6 @@ int ns_gemm_ln(const ns_gemm_ln_desc* d, void* stream);
 /* A/B knob for benchmarks: 1 (default) = automatic kernel choice, 0 = register-staged kernel only; 2..5 force one of
  * the wide NT kernels (see ns_gemm.hip), 6 = automatic without the small-M split-K kernel */
 void ns_debug_set_ring(int on);
-/* A/B knob: bit mask of the large-M launch classes that take the two-workgroups-per-CU kernel (csrc/ns_gemm_p4.hip; the NS_P4 environment
- * variable sets the same mask): 1 plain, 2 GELU, 4 GELU + side product, 8 fp32 residual, 16 x gelu' / x P16, 32 the same with the adapter
- * product under dropout, 64 plain with the adapter product under dropout.  Outputs are bit-identical whatever the mask. */
-void ns_debug_set_p4(int mask);
 /* A/B knob (NS_AD_SELF sets the same): which kernel ns_attn_decode's ancestry-layout launches (the decode loop's self-attention) take:
  * 1 (default) = one wave per (row, head) when groups * H > 2048, else the four-wave kernel of the cross-attention layout; 0 = never the
  * wave-per-head form; 2 = always.  Outputs agree up to fp32 summation order. */
@@ -182,17 +178,6 @@ int ns_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
 int ns_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* dres, float* dx32, void* dx16, int rows, int d,
                      void* stream);
-/* LayerNorm forward fused with the LoRA down-projection of the Linear it feeds (peft lora.Linear.forward:
- * lora_A(dropout(x)), finetune.py:205-212; HF:modeling_whisper.py:392,402 feed q|k|v and fc1):
- *   y16 = LN(x) exactly as ns_layernorm_fwd;  u16[m][j] = round16(alpha * sum_k keep(seed, m, k) * y16[m][k] * A16[j][k]),
- * j < n_out (32, or 96 = the stacked q|k|v adapters), A16 row-major with row stride lda.  One pass over x instead of a
- * LayerNorm launch plus a second pass over its 2*d bytes per row; u16 is bitwise what ns_gemm's streaming down-projection
- * produces from y16.  d = 256 or 512 (ns_layernorm_fwd_lora_supported); drop_p / drop_seed / seed_dev as in ns_gemm_desc. */
-int ns_layernorm_fwd_lora_supported(int rows, int d, int n_out);
-int ns_layernorm_fwd_lora(const float* x, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
-                          int rows, int d, float eps, const void* A16, int lda, int n_out, void* u16, int ldu, float alpha,
-                          float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
-
 /* ------------------------------------------------------------------------
  * ns_signal_pack: the MEG batch (B, ch, T) fp32 exactly as the collator emits
  * it (utils/data_utils.py:191-193) -> (B, T+2, Cp) fp16 token-major with zero

@@ -358,8 +358,6 @@ int ns_gemm_ring256_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_p8_launch(const ns_gemm_desc* d, hipStream_t st);
 int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_p8s_ok(const ns_gemm_desc* d);
-int ns_gemm_p4_launch(const ns_gemm_desc* d, hipStream_t st);
-bool ns_gemm_p4_ok(const ns_gemm_desc* d);
 bool ns_gemm_p8_fits(const ns_gemm_desc* d);
 int ns_gemm_smallm_launch(const ns_gemm_desc* d, hipStream_t st);
 bool ns_gemm_smallm_ok(const ns_gemm_desc* d);
@@ -375,28 +373,6 @@ bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 #endif
 static int g_use_ring = 1;
 extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
-// Which large-M launch classes take the two-workgroups-per-CU kernel (csrc/ns_gemm_p4.hip) instead of ns_gemm_p8 / p8s; bit-identical
-// outputs either way, the choice is per class by same-box measurement.  Bits: 1 plain, 2 GELU, 4 GELU + side product,
-// 8 fp32 residual, 16 x gelu' / x P16, 32 the same with the adapter product under dropout, 64 plain with the adapter product under dropout.
-#ifndef NS_P4_DEFAULT
-#define NS_P4_DEFAULT 0
-#endif
-static int g_p4_mask = -1;
-extern "C" void ns_debug_set_p4(int mask) { g_p4_mask = mask; }
-static int p4_mask() {
-  if (g_p4_mask < 0) {
-    const char* e = getenv("NS_P4");
-    g_p4_mask = e ? atoi(e) : NS_P4_DEFAULT;
-  }
-  return g_p4_mask;
-}
-static int p4_class(const ns_gemm_desc* d) {
-  const bool drop = d->drop_p > 0.f;
-  if (d->H32) return 8;
-  if (d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) return drop ? 32 : 16;
-  if (d->flags & NS_GEMM_GELU) return d->side_B ? 4 : 2;
-  return drop ? 64 : 1;
-}
 
 // the shapes the phase-interleaved 256 x 256 kernel takes in automatic mode, with whole 256-column tiles
 extern "C" int ns_gemm_side_supported(int M, int N, int K) {
@@ -532,8 +508,7 @@ extern "C" int ns_gemm(const ns_gemm_desc* d, void* stream) {
     // the persistent form (one workgroup per CU walks its tiles, epilogue / next-prologue overlap) where its 32-bit epilogue addressing
     // applies and a CU gets about three or more tiles (NS_P8S_MIN_TILES; below that the one-tile form with its dynamic tile order is as fast or faster); mode 4 forces the one-tile-per-workgroup form (A/B runs)
     const bool pers = big && p8_ok && ((g_use_ring == 1 && tiles256 >= NS_P8S_MIN_TILES && !(d->flags & (1 << 27))) || g_use_ring == 9) && ns_gemm_p8s_ok(d);
-    if (big && p8_ok && g_use_ring == 1 && !(d->flags & (1 << 27)) && (p4_mask() & p4_class(d)) && ns_gemm_p4_ok(d)) rc = ns_gemm_p4_launch(d, st);
-    else if (pers) rc = ns_gemm_p8s_launch(d, st);
+    if (pers) rc = ns_gemm_p8s_launch(d, st);
     else if (big && p8_ok && (g_use_ring == 4 || g_use_ring == 1 || g_use_ring == 9)) rc = ns_gemm_p8_launch(d, st);
     else {
       // only ns_gemm_p8_kernel forms the side product: any other kernel would leave side_out unwritten and the caller's

@@ -104,134 +104,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-// ---- LayerNorm forward + the LoRA down-projection of the Linear it feeds, in ONE pass over the residual stream:
-//        y16 = LN(x)  (the rows, statistics and roundings of ln_fwd_kernel, bit for bit)
-//        u16 = round16(alpha * drop(y16) A^T)      (peft lora.Linear.forward: lora_A(dropout(x)); finetune.py:205-212)
-// The unfused step ran ns_gemm_skinny right behind every such LayerNorm: a second pass over the 98 MB it had just written
-// (25-33 us per site at M = 96 000, 12 sites per step).  Here a 512-thread workgroup takes 32 rows per iteration: each wave
-// normalises four rows exactly as ln_fwd_kernel does (one wave per row, row in registers, same reduction tree), stores y16, and
-// drops a MASKED fp16 copy into a 32-row LDS tile; after one barrier the waves multiply the tile with A^T, which sits in LDS
-// for the whole launch in ns_gemm_skinny's [k / 8][n] layout, with ns_gemm_skinny's products in ns_gemm_skinny's order -- u16 is
-// bitwise what the unfused pair produces (tests/test_kernels_gpu.py).  The next 32 rows are requested before the barrier.
-// Tile: 16-B chunk c of row r sits at chunk c ^ (r & 15): conflict-free for the ds_write_b64 of a row and for the
-// ds_read_b128 operand reads (lane = row, the k slice of ns_gemm_skinny's permuted reduction order).
-template <int VEC, int NTILES, bool DROP>
-__global__ __launch_bounds__(512, 1) void ln_fwd_lora_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, half_t* __restrict__ y16,
-                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
-                                                             float eps, const half_t* __restrict__ A16, int lda, half_t* __restrict__ u16,
-                                                             int ldu, float alpha, float drop_p, uint32_t drop_seed,
-                                                             const uint32_t* __restrict__ seed_dev) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ll_lds[];
-  constexpr int d = 64 * VEC, N = 16 * NTILES, SS = d / 64;
-  constexpr int AT_BYTES = d * N * 2, ROWB = d * 2;
-  unsigned char* const at = ll_lds;
-  unsigned char* const tile = ll_lds + AT_BYTES;           // 32 rows x d fp16
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lg = lane >> 4;
-  const uint32_t dseed = DROP ? ns_eff_seed(drop_seed, seed_dev) : 0u;
-  const uint32_t thr = DROP ? ns_drop_thr8(drop_p) : 0u;
-  const int nblk = (rows + 31) >> 5;
-
-  float4 xin[4][VEC / 4];
-  auto request = [&](int blk) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = min(blk * 32 + 4 * wave + j, rows - 1);
-#pragma unroll
-      for (int i = 0; i < VEC / 4; ++i) xin[j][i] = *(const float4*)(x + (size_t)row * d + (i * 64 + lane) * 4);
-    }
-  };
-  int blk = blockIdx.x;
-  if (blk < nblk) request(blk);
-  // A^T -> LDS once: piece (kc, n) = A[n][8 kc .. 8 kc + 7] at byte 16 * (kc * N + n)
-  for (int q = tid; q < (d >> 3) * N; q += 512) {
-    const int kc = q / N, n = q - kc * N;
-    *(half8*)(at + 16 * q) = *(const half8*)(A16 + (size_t)n * lda + 8 * kc);
-  }
-  float4 gm[VEC / 4], bt[VEC / 4];
-#pragma unroll
-  for (int i = 0; i < VEC / 4; ++i) {
-    gm[i] = *(const float4*)(gamma + (i * 64 + lane) * 4);
-    bt[i] = *(const float4*)(beta + (i * 64 + lane) * 4);
-  }
-  for (; blk < nblk; blk += gridDim.x) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rl = 4 * wave + j, row = blk * 32 + rl;
-      float v[VEC];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC / 4; ++i) {
-        const float4 t = xin[j][i];
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-        s += (t.x + t.y) + (t.z + t.w);
-      }
-      const float mean = ns_wave_sum(s) / d;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { const float c = v[i] - mean; q += c * c; }
-      const float rstd = rsqrtf(ns_wave_sum(q) / d + eps);
-      const bool live = row < rows;
-      if (lane == 0 && live) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
-      }
-#pragma unroll
-      for (int i = 0; i < VEC / 4; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        float4 o;
-        o.x = (v[4 * i] - mean) * rstd * gm[i].x + bt[i].x;
-        o.y = (v[4 * i + 1] - mean) * rstd * gm[i].y + bt[i].y;
-        o.z = (v[4 * i + 2] - mean) * rstd * gm[i].z + bt[i].z;
-        o.w = (v[4 * i + 3] - mean) * rstd * gm[i].w + bt[i].w;
-        const half4 h = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
-        if (live) *(half4*)(y16 + (size_t)row * d + c) = h;
-        uint2 w = __builtin_bit_cast(uint2, h);
-        if (DROP) {
-          uint32_t m01, m23;
-          ns_keep_masks(ns_drop_word(dseed, (uint32_t)min(row, rows - 1), (uint32_t)c >> 2), thr, m01, m23);
-          w.x &= m01; w.y &= m23;
-        }
-        const int chunk = c >> 3;
-        *(uint2*)(tile + rl * ROWB + ((chunk ^ (rl & 15)) << 4) + (c & 4) * 2) = w;
-      }
-    }
-    const int nb = blk + gridDim.x;
-    if (nb < nblk) request(nb);                     // the next rows travel while this tile is multiplied
-    __syncthreads();
-    // (m tile, n tile) pairs over the eight waves: u[32 blk + 16 m + lr][16 j + 4 lg + e]
-#pragma unroll
-    for (int pp = 0; pp < (2 * NTILES + 7) / 8; ++pp) {
-      const int pr = wave + 8 * pp;
-      if (pr < 2 * NTILES) {
-        const int m = pr & 1, j = pr >> 1;
-        const int rl = 16 * m + lr;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < SS; ++s) {
-          const int c0 = 8 * s + 2 * lg;
-          const half8 x0 = *(const half8*)(tile + rl * ROWB + (((c0) ^ (rl & 15)) << 4));
-          const half8 x1 = *(const half8*)(tile + rl * ROWB + (((c0 + 1) ^ (rl & 15)) << 4));
-          const unsigned char* const bs = at + 16 * ((8 * s + 2 * lg) * N + lr) + 256 * j;
-          const half8 b0 = *(const half8*)bs;
-          const half8 b1 = *(const half8*)(bs + 16 * N);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, x0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, x1, acc, 0, 0, 0);
-        }
-        const int row = blk * 32 + rl;
-        if (row < rows) {
-          half4 h;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = (half_t)(acc[e] * alpha);
-          *(half4*)(u16 + (size_t)row * ldu + 16 * j + 4 * lg) = h;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
 }  // namespace
 
 extern "C" int ns_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32,
@@ -275,42 +147,5 @@ extern "C" int ns_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, c
   }
 #undef LNB
   NS_CHECK_LAUNCH("ns_layernorm_bwd");
-  return NS_OK;
-}
-
-// fused LayerNorm + LoRA down-projection (see ln_fwd_lora_kernel): d = 256 or 512, n_out = 32 or 96 rows of A16
-extern "C" int ns_layernorm_fwd_lora_supported(int rows, int d, int n_out) {
-  return rows >= 32 && (d == 256 || d == 512) && (n_out == 32 || n_out == 96) && (size_t)d * n_out * 2 + 32 * (size_t)d * 2 <= 160 * 1024;
-}
-
-extern "C" int ns_layernorm_fwd_lora(const float* x, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
-                                     int rows, int d, float eps, const void* A16, int lda, int n_out, void* u16, int ldu, float alpha,
-                                     float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream) {
-  NS_CHECK_ARG(x && gamma && beta && y16 && A16 && u16, "ns_layernorm_fwd_lora: null pointer");
-  NS_CHECK_ARG(ns_layernorm_fwd_lora_supported(rows, d, n_out), "ns_layernorm_fwd_lora: unsupported rows=%d d=%d n_out=%d", rows, d, n_out);
-  NS_CHECK_ARG(lda >= d && lda % 8 == 0 && ldu >= n_out && ldu % 4 == 0, "ns_layernorm_fwd_lora: bad strides lda=%d ldu=%d", lda, ldu);
-  NS_CHECK_ARG(drop_p >= 0.f && drop_p <= 0.5f, "ns_layernorm_fwd_lora: drop_p out of range (0 .. 0.5)");
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = (rows + 31) / 32;
-  const int grid = nblk < 256 ? nblk : 256;
-  const size_t lds = (size_t)d * n_out * 2 + 32 * (size_t)d * 2;
-  const float a = alpha == 0.f ? 1.f : alpha;
-#define LNL(VEC_, NT_, DR_)                                                                                                              \
-  do {                                                                                                                                   \
-    static ns_dev_once once;                                                                                                             \
-    if (!ns_dyn_lds_once(once, {(const void*)ln_fwd_lora_kernel<VEC_, NT_, DR_>}, 160 * 1024, "ns_layernorm_fwd_lora")) return NS_ERR_HIP; \
-    hipLaunchKernelGGL((ln_fwd_lora_kernel<VEC_, NT_, DR_>), dim3(grid), dim3(512), lds, st, x, gamma, beta, (half_t*)y16, mean, rstd, rows, \
-                       eps, (const half_t*)A16, lda, (half_t*)u16, ldu, a, drop_p, drop_seed, seed_dev);                                  \
-  } while (0)
-  const bool drop = drop_p > 0.f;
-  if (d == 512) {
-    if (n_out == 32) { if (drop) LNL(8, 2, true); else LNL(8, 2, false); }
-    else { if (drop) LNL(8, 6, true); else LNL(8, 6, false); }
-  } else {
-    if (n_out == 32) { if (drop) LNL(4, 2, true); else LNL(4, 2, false); }
-    else { if (drop) LNL(4, 6, true); else LNL(4, 6, false); }
-  }
-#undef LNL
-  NS_CHECK_LAUNCH("ns_layernorm_fwd_lora");
   return NS_OK;
 }

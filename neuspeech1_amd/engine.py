@@ -213,11 +213,6 @@ class MegWhisperEngine:
         self.label_pad = int(os.environ.get("NS_LABEL_PAD", 16))
         self.no_fused_lora_bwd = False      # tests / A-B runs: keep the two-GEMM backward of the adapter up-projections
         self.no_side_u2 = os.environ.get("NS_NO_SIDE_U2") == "1"   # tests / A-B runs: fc2's adapter bottleneck by its own pass over the GELU output
-        # LayerNorm fused with the adapter down-projection it feeds (ns_layernorm_fwd_lora, bitwise the two launches' results): OFF by
-        # default.  Measured in round 4: 25 % faster than the pair on cold operands, but inside the step both launches are served by the
-        # Infinity Cache (the LayerNorm input was just written) and the one-workgroup-per-CU fused kernel takes 68 / 77 us against
-        # 24 + 25 / 24 + 33 us (profiles/r4_a_bench_kernel_stats.csv).  NS_LN_LORA=1 turns it on.
-        self.no_ln_lora = os.environ.get("NS_LN_LORA") != "1"
         # residual Linear + the LayerNorm that reads its result in one launch (ns_gemm_ln: d = 512, bitwise the two launches' results).
         # NS_ROWLN: 0 = ns_gemm + ns_layernorm_fwd everywhere, 1 = every residual Linear with d = 512, 2 (default) = only the K = 512
         # out-projection.  Measured (round 5, same box, M = 96 000): K = 512 163.5 us against 166.6 us for the two launches; K = 2048 (fc2)
@@ -732,12 +727,6 @@ class MegWhisperEngine:
         dp = self._drop_p()
         rank = r
 
-        def fuse_ln_at(i):
-            """LayerNorm + the adapter bottleneck of the Linear it feeds in ONE pass (ns_layernorm_fwd_lora; NS_LN_LORA=1, off by default)"""
-            ri = rank if i < self.n_lora else 0
-            return bool(ri) and not self.no_ln_lora and ops.layernorm_fwd_lora_supported(M, d, 3 * ri) and \
-                ops.layernorm_fwd_lora_supported(M, d, ri)
-
         def lin_ln(x16, lin, R32, H32, ln, xout, st, A2=None, lda2=0, K2=0, B2=None):
             """residual Linear + the LayerNorm that reads its result: one launch (ns_gemm_ln, bitwise the pair's results) where built"""
             # (only where ns_gemm itself takes the phase-interleaved 256 x 256 kernel -- >= 192 tiles --, whose products ns_gemm_ln repeats
@@ -762,17 +751,12 @@ class MegWhisperEngine:
                 hin, hmid, hout = h[0], h[1], h[0]
             lo = self.lora_ops[i] if r else None
             seed = self._layer_seed(i)
-            fuse_ln = fuse_ln_at(i)
-            if fuse_ln:
-                ops.layernorm_fwd_lora(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d, lo["Aqkv"], d, 3 * r, b["uqkv"][j], 3 * r,
-                                       alpha=self._drop_inv(), drop_p=dp, drop_seed=seed, seed_dev=self.seed_ctr if dp > 0 else None)
-            elif not ln1_done:      # (the previous layer's fc2 launch normalised this layer's input already)
+            if not ln1_done:      # (else the previous layer's fc2 launch normalised this layer's input already)
                 ops.layernorm_fwd(hin, *Lw["ln1"], b["x1"][j], *b["st1"][j], M, d)
             ln1_done = False
             if r:
-                if not fuse_ln:
-                    self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
-                             c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
+                self._gemm(A=b["x1"][j], am=rowmap(d), K=d, B=lo["Aqkv"], ldb=d, M=M, N=3 * r, C16=b["uqkv"][j],
+                         c16m=rowmap(3 * r), flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed)
                 self._lin(b["x1"][j], M, Lw["qkv"], C16=b["qkv"][j], A2=b["uqkv"][j], lda2=3 * r, K2=r, B2=lo["sBqkv"],
                           ngroup=d)
             else:
@@ -784,30 +768,21 @@ class MegWhisperEngine:
             if r:
                 self._gemm(A=b["ao"][j], am=rowmap(d), K=d, B=lo["out_A"], ldb=d, M=M, N=r, C16=b["uo"][j], c16m=rowmap(r),
                          flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 1)
-            if fuse_ln:
-                self._lin(b["ao"][j], M, Lw["out"], R32=hin, H32=hmid, **ad)
-                ops.layernorm_fwd_lora(hmid, *Lw["ln2"], b["x2"][j], *b["st2"][j], M, d, lo["fc1_A"], d, r, b["u1"][j], r,
-                                       alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2, seed_dev=self.seed_ctr if dp > 0 else None)
-            else:
-                lin_ln(b["ao"][j], Lw["out"], hin, hmid, Lw["ln2"], b["x2"][j], b["st2"][j], **ad)
+            lin_ln(b["ao"][j], Lw["out"], hin, hmid, Lw["ln2"], b["x2"][j], b["st2"][j], **ad)
             # fc2's result feeds the NEXT layer's first LayerNorm (or the encoder's final one)
             if i + 1 < ne:
                 jn = i + 1 if train else 0
-                nxt = None if fuse_ln_at(i + 1) else (self.enc[i + 1]["ln1"], b["x1"][jn], b["st1"][jn])
+                nxt = (self.enc[i + 1]["ln1"], b["x1"][jn], b["st1"][jn])
             else:
                 nxt = (self.enc_ln, b["enc16"], b["enc_st"])
 
             def fc2(**ad2):
                 nonlocal ln1_done, final_done
-                if nxt is None:
-                    self._lin(b["gf"][j], M, Lw["fc2"], R32=hmid, H32=hout, **ad2)
-                    return
                 lin_ln(b["gf"][j], Lw["fc2"], hmid, hout, *nxt, **ad2)
                 ln1_done, final_done = i + 1 < ne, i + 1 == ne
             if r:
-                if not fuse_ln:
-                    self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
-                             flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
+                self._gemm(A=b["x2"][j], am=rowmap(d), K=d, B=lo["fc1_A"], ldb=d, M=M, N=r, C16=b["u1"][j], c16m=rowmap(r),
+                         flags=NS_GEMM_DROP_A if dp > 0 else 0, alpha=self._drop_inv(), drop_p=dp, drop_seed=seed + 2)
                 side = train and "u2_slabs" in b and not self.no_side_u2
                 sk = dict(side_B=lo["fc2_A"], side_ldb=f, side_n=r, side_out=b["u2_slabs"], side_drop_p=dp,
                           side_drop_seed=seed + 3) if side else {}
@@ -1206,7 +1181,7 @@ class MegWhisperEngine:
         # feed's few staging slots and is captured by address.
         import dataclasses
         key = (tuple(x32.shape), tuple(labels.shape), x32.xin.data_ptr() if packed else 0, cut, dataclasses.astuple(self.tc),
-               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs, self.no_ln_lora,
+               self.lora.dropout if self.lora else 0.0, self.drop_seed, self.no_fused_lora_bwd, self.train_convs,
                self.use_rowln)
         g = self._graphs.get(key)
         if g is None:
@@ -1274,7 +1249,7 @@ class MegWhisperEngine:
         if not (self.use_graph and self.dev.type == "cuda"):
             return False
         # the bench's instrumentation (events around every GEMM / section marks) belongs to eager steps
-        return ops.GEMM_PROFILE is None and getattr(self, "section_events", None) is None
+        return ops.GEMM_PROFILE is None and ops.STEP_PROFILE is None and getattr(self, "section_events", None) is None
 
     def _capture_step(self, x32, labels, cut: bool):
         """Capture one training step.  Nothing executes during capture: the caller replays the segments afterwards.

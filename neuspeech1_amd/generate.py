@@ -75,7 +75,6 @@ class Generator:
         # beam-5), so only generations with >= 128 steps left (whisper's max_length is 448) capture
         import os
         self.graph_min_steps = int(os.environ.get("NS_GRAPH_MIN_STEPS", 128)) if graph_min_steps is None else graph_min_steps
-        self.split_graph_min_steps = int(os.environ.get("NS_SPLIT_GRAPH_MIN_STEPS", 16))
         self.use_lists = os.environ.get("NS_LAUNCH_LISTS", "1") != "0"      # recorded launch lists for generations too short for graphs
         self.adaptive = os.environ.get("NS_DECODE_ADAPT", "1") != "0"       # lists -> hipGraphs when the replays turn out host-bound
         self.adaptive_min_steps = int(os.environ.get("NS_DECODE_ADAPT_MIN_STEPS", 24))
@@ -134,13 +133,11 @@ class Generator:
         Bp = B * nb
         max_len = min(P + max_new_tokens, dims.tgt_pos)
         fewq = self.cross_mfma and 1 < nb <= 16
-        nsplit = int(os.environ.get("NS_DECODE_SPLIT", "0")) or 1
-        nsplit = max(1, min(nsplit, B))
         fused_select = dims.vocab_pad <= ops.SELECT_MAX_LDV and os.environ.get("NS_NO_FUSED_SELECT") != "1"
         # ---- the session of this call signature (everything a recorded / captured launch has baked into it)
         key = None
         if self.cache_sessions and trace is None and dev.type == "cuda":
-            key = (B, P, nb, max_len, nsplit, fewq, fused_select, float(repetition_penalty), int(no_repeat_ngram_size),
+            key = (B, P, nb, max_len, fewq, fused_select, float(repetition_penalty), int(no_repeat_ngram_size),
                    tuple(int(t) for t in suppress_tokens), tuple(int(t) for t in begin_suppress_tokens), float(length_penalty), eos, pad,
                    repr(forced_decoder_ids), begin_index, repr(sequence_bias), str(dev), torch.cuda.current_stream().cuda_stream,
                    self._weights_fingerprint())
@@ -208,32 +205,13 @@ class Generator:
         # processors + per-row top-k in one pass, no fp32 score matrix (a sequence bias takes the two-kernel form)
         scores = None if fused_select else T("scores", lambda: torch.empty(Bp, V, device=dev, dtype=F32))
 
-        # Row ranges of the batch as independent chains on separate streams: a decode step is a serial chain in
-        # which the HBM-bound cross-attention (393 MB per layer at B = 128, ~5.5 TB/s) and the latency-bound small-M projections /
-        # LayerNorms alternate, each leaving the other resource idle; with the sequences cut into `nsplit` ranges that run the
-        # six layers on a stream each, one range could stream its cross K/V while the others are in their projection chains.
-        # Every kernel is row-independent, the ranges join before the final LayerNorm / LM head / selection, ids are identical
-        # (tests/test_generate_gpu.py::test_split_decode_chains_give_the_same_ids).  MEASURED (round 5, B = 128, 64 new tokens,
-        # same box): greedy 105.9 k tokens/s with one chain, 85.6 k with two, 74.6 k with four; beam-5 82.3 / 75.5 / 66.0 k.
-        # The branches of a replayed hipGraph DO run concurrently on this stack (tools/probe/graph_branch_overlap.py: two chains
-        # of 65-us launches take 20.7 ms against 39.2 ms on one stream), but a decode step's launches are 4-9 us each: a range's
-        # chain costs as many launches whatever its row count, so two chains are twice the launches for the same dispatch rate,
-        # and the cross-attention stream, already at 5.5 TB/s, has nothing to gain from sharing the pipe.  Launched eagerly two
-        # chains are host-bound (55.5 k).  OFF by default; NS_DECODE_SPLIT=n turns it on.
-        cuts = [B * k // nsplit for k in range(nsplit + 1)]
-        side = [torch.cuda.Stream(dev) for _ in range(nsplit - 1)] if dev.type == "cuda" else []
-        self.last_split = nsplit
-
-        # row-range views, made ONCE per generation: the loop below runs eagerly for short generations, and a dozen tensor slices per
-        # step (~1.5 us each on the host) were enough to make a 0.84-ms step host-bound (1.00 ms measured with the slices in the loop)
-        parts = []
-        for k in range(nsplit):
-            s0_, s1_ = cuts[k], cuts[k + 1]
-            r0_, r1_ = s0_ * nb, s1_ * nb
-            parts.append(dict(s0=s0_, s1=s1_, r0=r0_, n=r1_ - r0_, h={id(t_): t_[r0_:r1_] for t_ in h}, x=x16[r0_:r1_], qkv=qkv[r0_:r1_],
-                              qc=qc[r0_:r1_], ao=ao[r0_:r1_], gf=gf[r0_:r1_], st=(st[0][r0_:r1_], st[1][r0_:r1_]),
-                              anc={id(t_): t_[r0_:r1_] for t_ in anc}, kx=[kv_[s0_ * S:s1_ * S] for kv_ in kvx],
-                              vt=[v_[s0_:s1_] for v_ in vtx]))
+        # (Row ranges of the batch as independent chains on separate streams -- VERDICT r4 #4 -- were built in round 5, gave identical ids and
+        # were SLOWER: greedy 105.9 k tokens/s with one chain, 85.6 k with two, 74.6 k with four; a range's chain costs as many 4-9 us launches
+        # whatever its row count.  Removed in round 6: tools/probe/attic/README.md, profiles/r5_probe_decode_split.log.)
+        # row views made ONCE per generation: the loop below runs eagerly for short generations, and a dozen tensor slices per step
+        # (~1.5 us each on the host) were enough to make a 0.84-ms step host-bound
+        whole = dict(s0=0, s1=B, r0=0, n=Bp, h={id(t_): t_ for t_ in h}, x=x16, qkv=qkv, qc=qc, ao=ao, gf=gf, st=st,
+                     anc={id(t_): t_ for t_ in anc}, kx=kvx, vt=vtx)
 
         def layers(pt: dict, t: int, a, c1):
             """the decoder layers for the sequences of one row range; results in h[0] / h[1] by layer-count parity"""
@@ -280,17 +258,7 @@ class Generator:
                 anc.reverse()
             a = anc[0]
             ops.embed_pos(tok, eng.E32, eng.dec_pos, h[0], Bp, 1, d, pos0=t, pos0_dev=c0)
-            if nsplit == 1:
-                layers(parts[0], t, a, c1)
-            else:
-                main = torch.cuda.current_stream()
-                for k, sd in enumerate(side):       # fork: every range starts behind the embedding
-                    sd.wait_stream(main)
-                    with torch.cuda.stream(sd):
-                        layers(parts[k + 1], t, a, c1)
-                layers(parts[0], t, a, c1)
-                for sd in side:                     # join
-                    main.wait_stream(sd)
+            layers(whole, t, a, c1)
             if len(eng.dec) % 2:
                 h.reverse()
             ops.layernorm_fwd(h[0], *eng.dec_ln, x16, *st, Bp, d)
@@ -418,13 +386,13 @@ class Generator:
                     step(next_tok, cur - 1, parent)
                     # two chains per step double the launches the host has to enqueue (~150 per step against ~0.6 ms of GPU time):
                     # with split chains the replayed graph is what keeps the loop GPU-bound, so even short generations capture
-                    gms = self.graph_min_steps if nsplit == 1 else min(self.graph_min_steps, self.split_graph_min_steps)
+                    gms = self.graph_min_steps
                     as_graph = graph_ok and max_len - cur >= gms
                     # Shorter generations replay LAUNCH LISTS instead (ops.LaunchList: the same two (select, feed) pairs recorded
                     # without being launched, exactly as a stream capture would; no hipGraph to instantiate): building ~80
                     # descriptors through ctypes costs the host 0.8-1.0 ms per step against 0.84 ms of GPU time -- the driver's
                     # 64-token eval leg ran host-bound on a slow host (100 k tokens/s against 108 k) -- and ~0.1 ms replayed.
-                    as_list = not as_graph and self.use_lists and nsplit == 1 and trace is None and max_len - cur >= 4
+                    as_list = not as_graph and self.use_lists and trace is None and max_len - cur >= 4
                     # A session that is called again (an evaluation loop: the same signature for every batch) replays what it holds --
                     # the hipGraphs, captured by the SECOND call of the signature whatever the generation's length, or the lists
                     if ws["graphs"] is None and graph_ok and key is not None and not first_call and max_len - cur >= 4:

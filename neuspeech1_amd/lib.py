@@ -186,14 +186,11 @@ SIGNATURES = {
     "ns_last_error": (C.c_char_p, []),
     "ns_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "ns_debug_set_ring": (None, [C.c_int]),
-    "ns_debug_set_p4": (None, [C.c_int]),
     "ns_debug_set_ad_self": (None, [C.c_int]),
     "ns_gemm_ln_supported": (C.c_int, [_i, _i, _i, _i]),
     "ns_gemm_ln": (C.c_int, [C.POINTER(GemmLnDesc), _vp]),
     "ns_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ns_layernorm_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "ns_layernorm_fwd_lora_supported": (C.c_int, [_i, _i, _i]),
-    "ns_layernorm_fwd_lora": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _i, _f, _f, C.c_uint32, _vp, _vp]),
     "ns_signal_pack": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ns_feed_pack": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ns_embed_pos": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

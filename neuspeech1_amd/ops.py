@@ -67,13 +67,33 @@ class recording:
         return False
 
 
+STEP_PROFILE = None   # set to a list by bench.py: every entry-point launch is then bracketed by HIP events on the launch stream and recorded as
+#                       (class, flop, algorithmic bytes, e0, e1); the class / work come from the wrapper (_work) or default to the entry point's name
+
+
+def _work(cls: str, flop: float = 0.0, nbytes: float = 0.0):
+    """wrapper -> _call: the class and the ALGORITHMIC work (FLOP, HBM bytes: every operand once) of the launch that follows"""
+    if STEP_PROFILE is not None:
+        _tls.work = (cls, float(flop), float(nbytes))
+
+
 def _call(name: str, *args):
     fn = getattr(L.load(), name)
     rec = getattr(_tls, "rec", None)
     if rec is not None:
         rec.calls.append((fn, name, args))
         return
+    if STEP_PROFILE is None:
+        L.check(fn(*args, _stream()), name)
+        return
+    work = getattr(_tls, "work", None) or (name[3:] if name.startswith("ns_") else name, 0.0, 0.0)
+    _tls.work = None
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
     L.check(fn(*args, _stream()), name)
+    e1.record(st)
+    STEP_PROFILE.append((*work, e0, e1))
 
 
 def ptr(t, off: int = 0) -> int:
@@ -120,27 +140,71 @@ def _fill_gemm_desc(d, *, A, am, K, B, ldb=None, bm=None, M, N, A2=None, am2=Non
     return d
 
 
+def _gemm_kind(kw) -> str:
+    """which kernel family ns_gemm dispatches this launch to (mirrors csrc/ns_gemm.hip)"""
+    M, N, flags = kw["M"], kw["N"], kw.get("flags", 0)
+    if flags & NS_GEMM_TN:
+        return "tn"
+    if N <= 96 or (M <= 1024 and N <= 4096):
+        return "nt32"
+    return "nt256" if (N >= 256 and (M >= 2048 or (M >= 128 and N >= 8192)) and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
+
+
+def _gemm_work(kw):
+    """(FLOP, algorithmic HBM bytes) of one ns_gemm launch: every operand and every output once.  A row-mapped A (the conv stem's overlapping
+    k = 3 windows over a halo image) counts the image once, not its three views."""
+    M, N, K, K2, flags = kw["M"], kw["N"], kw["K"], kw.get("K2", 0), kw.get("flags", 0)
+    side = kw.get("side_n", 0) if kw.get("side_B") is not None else 0      # side product: 2 M N side_n more
+    flop = 2.0 * M * N * ((kw.get("k_alg") or K) + K2 + side)
+    am = kw.get("am")
+    if flags & NS_GEMM_TN:      # C32 (M x N) += A^T B over K reduction rows: A is (K, M), B is (K, N)
+        by = 2.0 * K * (M + N) + 4.0 * M * N
+        return flop, by
+    if am is not None and am.seg_rows > 0 and am.ld < K:      # overlapping rows: the (segments x seg_stride) image once
+        a_bytes = 2.0 * (M / am.seg_rows) * am.seg_stride
+    else:
+        a_bytes = 2.0 * M * K
+    by = a_bytes + 2.0 * N * K + 2.0 * (M + N) * K2
+    for name, w in (("C16", 2), ("G16", 2), ("P16", 2), ("R32", 4), ("H32", 4), ("C32", 4)):
+        if kw.get(name) is not None:
+            by += float(w) * M * N
+    if kw.get("bias") is not None:
+        by += 4.0 * N
+    if side:
+        by += 2.0 * side * N + 4.0 * ((N + 255) // 256) * M * side
+    return flop, by
+
+
+def _gemm_epi(kw) -> str:
+    flags = kw.get("flags", 0)
+    e = "res" if kw.get("H32") is not None else ("dgelu" if flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16) else ("gelu" if flags & NS_GEMM_GELU else "plain"))
+    if kw.get("side_B") is not None:
+        e += "+side"
+    if kw.get("K2", 0):
+        e += "+k2"
+    if kw.get("drop_p", 0.0) > 0.0:
+        e += "+drop"
+    return e
+
+
 def gemm(**kw):
     """ns_gemm (keyword arguments = the descriptor's fields, see _fill_gemm_desc).  k_alg: the ALGORITHMIC reduction length where K
     carries padding (the first conv: 3 x ch against 3 x ch_pad); only the bench's FLOP count reads it"""
     d = _fill_gemm_desc(GemmDesc(), **kw)
+    if STEP_PROFILE is not None:
+        kind = _gemm_kind(kw)
+        _work(f"gemm {kind} {_gemm_epi(kw)} K={kw['K']} N={kw['N']}" if kind == "nt256" else f"gemm {kind}", *_gemm_work(kw))
     if GEMM_PROFILE is None:
         _call("ns_gemm", C.byref(d))
         return
     # bench.py roofline leg: HIP events on the launch stream around every GEMM launch
-    M, N, K, K2, flags = kw["M"], kw["N"], kw["K"], kw.get("K2", 0), kw.get("flags", 0)
-    if flags & NS_GEMM_TN:
-        kind = "tn"
-    elif N <= 96 or (M <= 1024 and N <= 4096):
-        kind = "nt32"
-    else:   # mirrors the dispatch in csrc/ns_gemm.hip
-        kind = "nt256" if (N >= 256 and (M >= 2048 or (M >= 128 and N >= 8192)) and ((M + 255) // 256) * ((N + 255) // 256) >= 192) else "nt128"
+    kind = _gemm_kind(kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
     _call("ns_gemm", C.byref(d))
     e1.record(torch.cuda.current_stream())
-    side = kw.get("side_n", 0) if kw.get("side_B") is not None else 0      # side product: 2 M N side_n more
-    GEMM_PROFILE.append((kind, 2.0 * M * N * ((kw.get("k_alg") or K) + K2 + side), e0, e1))
+    fl, by = _gemm_work(kw)
+    GEMM_PROFILE.append((kind, fl, e0, e1, by))
 
 
 def gemm_ln_supported(M: int, N: int, K: int, K2: int = 0) -> bool:
@@ -153,6 +217,9 @@ def gemm_ln(*, gamma, beta, x16, ldx, mean=None, rstd=None, eps=1e-5, **kw):
     _fill_gemm_desc(q.g, **kw)
     q.gamma, q.beta, q.eps, q.ldx = ptr(gamma), ptr(beta), eps, ldx
     q.x16, q.mean, q.rstd = ptr(x16), ptr(mean), ptr(rstd)
+    fl, by = _gemm_work(kw)
+    by += kw["M"] * (2.0 * kw["N"] + 8.0)      # + the LayerNorm's x16 row and its statistics
+    _work("gemm rowln (+LayerNorm)", fl, by)
     if GEMM_PROFILE is None:
         _call("ns_gemm_ln", C.byref(q))
         return
@@ -160,7 +227,7 @@ def gemm_ln(*, gamma, beta, x16, ldx, mean=None, rstd=None, eps=1e-5, **kw):
     e0.record(torch.cuda.current_stream())
     _call("ns_gemm_ln", C.byref(q))
     e1.record(torch.cuda.current_stream())
-    GEMM_PROFILE.append(("rowln", 2.0 * kw["M"] * kw["N"] * (kw["K"] + kw.get("K2", 0)), e0, e1))
+    GEMM_PROFILE.append(("rowln", fl, e0, e1, by))
 
 
 def gemm_side_supported(M: int, N: int, K: int) -> bool:
@@ -168,31 +235,25 @@ def gemm_side_supported(M: int, N: int, K: int) -> bool:
 
 
 def gemm_side_reduce(slabs, tiles, M, alpha, u16, ldu):
+    _work("side_reduce", 0.0, M * 32 * (4.0 * tiles + 2.0))
     _call("ns_gemm_side_reduce", ptr(slabs), tiles, M, alpha, ptr(u16), ldu)
 
 
 def layernorm_fwd(x32, gamma, beta, y16, mean, rstd, rows, d, y32=None, eps=1e-5):
+    _work("layernorm_fwd", 0.0, rows * (d * (6.0 + (4.0 if y32 is not None else 0.0)) + 8.0))
     _call("ns_layernorm_fwd", ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean), ptr(rstd),
                                       rows, d, eps)
 
 
-def layernorm_fwd_lora_supported(rows, d, n_out):
-    return bool(L.load().ns_layernorm_fwd_lora_supported(rows, d, n_out))
-
-
-def layernorm_fwd_lora(x32, gamma, beta, y16, mean, rstd, rows, d, A16, lda, n_out, u16, ldu, alpha=1.0, drop_p=0.0, drop_seed=0,
-                       seed_dev=None, eps=1e-5):
-    """y16 = LN(x32) and u16 = round16(alpha * drop(y16) A16^T) in one pass (ns_layernorm_fwd_lora)"""
-    _call("ns_layernorm_fwd_lora", ptr(x32), ptr(gamma), ptr(beta), ptr(y16), ptr(mean), ptr(rstd), rows, d, eps, ptr(A16), lda,
-                                           n_out, ptr(u16), ldu, alpha, drop_p, int(drop_seed) & 0xFFFFFFFF, ptr(seed_dev))
-
-
 def layernorm_bwd(dy, dy_is_f32, x32, mean, rstd, gamma, dres, dx32, dx16, rows, d):
+    _work("layernorm_bwd", 0.0, rows * (d * ((4.0 if dy_is_f32 else 2.0) + 4.0 + (4.0 if dres is not None else 0.0)
+                                              + (4.0 if dx32 is not None else 0.0) + (2.0 if dx16 is not None else 0.0)) + 8.0))
     _call("ns_layernorm_bwd", ptr(dy), int(dy_is_f32), ptr(x32), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
                                       ptr(dx32), ptr(dx16), rows, d)
 
 
 def signal_pack(x32, out16, B, ch, T, Cp):
+    _work("signal_pack", 0.0, B * (4.0 * ch * T + 2.0 * (T + 2) * Cp))
     _call("ns_signal_pack", ptr(x32), ptr(out16), B, ch, T, Cp)
 
 
@@ -228,8 +289,19 @@ def _attn_desc(Q, K, V, O, B, H, Lq, Lk, ldq, ldk, ldv, ldo, causal, LSE=None, d
     return d
 
 
+def _attn_work(kw, bwd: bool):
+    B, H, Lq, Lk = kw["B"], kw["H"], kw["Lq"], kw["Lk"]
+    causal = bool(kw.get("causal"))
+    fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
+    by = 2.0 * B * H * 64 * (2 * Lq + 2 * Lk) + 4.0 * B * H * Lq         # Q, O, K, V + LSE
+    if bwd:
+        return 2.5 * fl, 2.0 * by + 4.0 * B * H * Lq                       # + dO, dQ, dK, dV, delta (five products against two)
+    return fl, by
+
+
 def attn_fwd(**kw):
     d = _attn_desc(**kw)
+    _work("attn_fwd" + (" causal" if kw.get("causal") else "") + (" (few queries)" if kw["Lq"] <= 64 else ""), *_attn_work(kw, False))
     _call("ns_attn_fwd", C.byref(d))
 
 
@@ -239,10 +311,13 @@ def attn_bwd_workspace_bytes(B, H, Lq, Lk, causal=False) -> int:
 
 def attn_bwd(**kw):
     d = _attn_desc(**kw)
+    _work("attn_bwd" + (" one pass" if kw.get("workspace") is not None and kw["Lq"] > 64 else "") + (" causal" if kw.get("causal") else "")
+          + (" (few queries)" if kw["Lq"] <= 64 else ""), *_attn_work(kw, True))
     _call("ns_attn_bwd", C.byref(d))
 
 
 def cross_entropy(logits16, labels, rows, V, ldv, row_loss, dlogits16, nvalid_dev, loss_scale_dev, loss_dev):
+    _work("cross_entropy", 0.0, rows * V * (2.0 + (2.0 if dlogits16 is not None else 0.0)))
     _call("ns_cross_entropy", ptr(logits16), ptr(labels), rows, V, ldv, ptr(row_loss), ptr(dlogits16),
                                       ptr(nvalid_dev), ptr(loss_scale_dev), ptr(loss_dev))
 
@@ -252,10 +327,12 @@ def argmax_rows(logits16, rows, V, ldv, out):
 
 
 def grad_norm(g32, n, workspace, norm2_dev, found_inf_dev):
+    _work("grad_norm", 0.0, 4.0 * n)
     _call("ns_grad_norm", ptr(g32), n, ptr(workspace), ptr(norm2_dev), ptr(found_inf_dev))
 
 
 def adamw_step(p, g, m, v, n, cfg: AdamWCfg, step_dev, norm2_dev, found_inf_dev, loss_scale_dev, growth_tracker_dev):
+    _work("adamw_step", 0.0, 28.0 * n)
     _call("ns_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), n, C.byref(cfg), ptr(step_dev), ptr(norm2_dev),
                                    ptr(found_inf_dev), ptr(loss_scale_dev), ptr(growth_tracker_dev))
 
@@ -269,6 +346,7 @@ def zero_(*tensors):
         for j, t in enumerate(chunk):
             assert t.is_contiguous()
             arr[j] = L.Span(t.data_ptr(), t.numel() * t.element_size())
+        _work("zero_spans", 0.0, float(sum(t.numel() * t.element_size() for t in chunk)))
         _call("ns_zero_spans", arr, len(chunk))
 
 
@@ -456,4 +534,5 @@ def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du
     d.M, d.N, d.r, d.G = M, N, r, G
     d.ldy, d.ldu, d.lddu, d.lddb = ldy, ldu, lddu, lddb
     d.alpha_du, d.splits = alpha_du, splits
+    _work("lora_bwd_dudb (+reduce)", 2.0 * M * G * N * r * 2, 2.0 * M * G * N + 2.0 * M * G * r * 2 + 2.0 * G * N * r + 4.0 * G * N * r)
     _call("ns_lora_bwd_dudb", C.byref(d))

@@ -145,20 +145,6 @@ def test_delayed_stop_check_gives_same_ids(setup):
 
 
 @pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
-def test_split_decode_chains_give_the_same_ids(setup, monkeypatch, nb, kw):
-    """NS_DECODE_SPLIT: the decoder layers of a step as row-range chains on separate streams (ns_attn_decode.slot0 appends each
-    range's K / V rows at its own cache slots), eager and replayed from graphs: the ids of the single chain, bit for bit."""
-    from neuspeech1_amd.generate import Generator
-    g, dims, gen, x, prompt = setup
-    ref = gen.generate(x, prompt, num_beams=nb, max_new_tokens=24, check_every=1, **kw)
-    for split, graph in ((2, False), (3, True)):
-        monkeypatch.setenv("NS_DECODE_SPLIT", str(split))
-        g2 = Generator(gen.eng, use_graph=graph, graph_min_steps=0)
-        out = g2.generate(x, prompt, num_beams=nb, max_new_tokens=24, check_every=1, **kw)
-        assert g2.last_split == split and torch.equal(out, ref), (split, graph)
-
-
-@pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
 def test_launch_lists_hand_over_to_graphs_when_the_host_is_the_bottleneck(setup, nb, kw):
     """A generation too short for graphs replays launch lists; when two polled chunks in a row spend most of their wall time
     inside the replays (a slow host: the runtime's own launch path, ~72 launches per step), the loop captures the hipGraphs

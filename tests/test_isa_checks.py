@@ -52,7 +52,7 @@ def _regs(tok):
 
 
 @pytest.mark.parametrize("src,kernel,count", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel", 2), ("ns_gemm_p8s.hip", "ns_gemm_p8s_kernel", 12),
-                                              ("ns_gemm_rowln.hip", "gemm_ln_kernel", 1), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel", 2)])
+                                              ("ns_gemm_rowln.hip", "gemm_ln_kernel", 1)])
 def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, kernel, count):
     kernels = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
     assert len(kernels) == count, list(kernels)
@@ -86,7 +86,7 @@ def test_p8_inline_asm_loads_are_not_touched_before_their_wait(tmp_path, src, ke
 
 @pytest.mark.parametrize("src,kernel", [("ns_gemm_p8.hip", "ns_gemm_p8_kernel"), ("ns_gemm_tn256.hip", "ns_gemm_tn256_kernel"),
                                         ("ns_lora_bwd.hip", "lora_bwd_dudb_kernel"), ("ns_attn.hip", "attn_fwd_kernel"),
-                                        ("ns_gemm_rowln.hip", "gemm_ln_kernel"), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel")])
+                                        ("ns_gemm_rowln.hip", "gemm_ln_kernel")])
 def test_hot_kernels_use_no_scratch(tmp_path, src, kernel):
     ks = {k: v for k, v in _kernels(_asm(src, tmp_path)).items() if kernel in k}
     assert ks, src
@@ -219,9 +219,9 @@ def test_attention_forward_tiles_travel_by_lds_dma_with_one_barrier_per_tile(tmp
     assert vg <= 128, vg
 
 
-@pytest.mark.parametrize("src,kernel,count,pieces", [("ns_gemm_rowln.hip", "gemm_ln_kernel", 1, 5), ("ns_gemm_p4.hip", "ns_gemm_p4_kernel", 2, 6)])
+@pytest.mark.parametrize("src,kernel,count,pieces", [("ns_gemm_rowln.hip", "gemm_ln_kernel", 1, 5)])
 def test_round5_gemm_k_loops_wait_counted_and_fit_two_waves_per_simd(tmp_path, src, kernel, count, pieces):
-    """ns_gemm_ln / ns_gemm_p4 (round 5): the K loop -- twelve 32-deep steps unrolled, 32 MFMAs and ONE barrier each -- holds only the
+    """ns_gemm_ln (round 5; ns_gemm_p4, the other kernel of this structure, moved to tools/probe/attic in round 6): the K loop -- twelve 32-deep steps unrolled, 32 MFMAs and ONE barrier each -- holds only the
     hand-counted wait that lets the newest step's pieces travel on (never vmcnt(0)), requests its operands by LDS-DMA (`pieces` per
     wave and step), and the kernel keeps to the 256 registers that put two waves on a SIMD."""
     asm = _asm(src, tmp_path)

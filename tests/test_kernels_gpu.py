@@ -317,45 +317,6 @@ def test_layernorm(ops, dev, rows, d):
         close(dx16, dx32.half(), 1e-6, 1e-6, "ln bwd16")
 
 
-@pytest.mark.parametrize("rows,d,n_out,p", [(12007, 512, 32, 0.05), (9000, 512, 96, 0.05), (8192, 512, 96, 0.0), (96000, 512, 96, 0.05),
-                                            (300, 256, 32, 0.05), (45, 256, 96, 0.0)])
-def test_layernorm_fused_with_lora_down_projection(ops, dev, rows, d, n_out, p):
-    """ns_layernorm_fwd_lora: LayerNorm and the adapter bottleneck u = alpha * drop(LN(x)) A^T of the Linear it feeds in one pass.
-    y16 and the row statistics must be BITWISE those of ns_layernorm_fwd (same rows, same reduction tree); u bitwise what the
-    separate down-projection launch (ns_gemm's streaming kernel, M >= 8192) makes of that y16 -- same products, same order -- and
-    against torch fp32 with the numpy restatement of the keep mask everywhere; device-resident seed counter, ragged row counts,
-    a strided destination."""
-    seed = 777
-    x = rnd((rows, d), dev, 2.0, torch.float32, seed=1) + 0.5
-    g = rnd((d,), dev, 1.0, torch.float32, seed=2)
-    b = rnd((d,), dev, 1.0, torch.float32, seed=3)
-    A = rnd((n_out, d), dev, 0.05, seed=4)
-    ctr = torch.tensor([3], device=dev, dtype=torch.int32)
-    eff = (seed + 3 * 0x9E3779B1) & 0xFFFFFFFF
-    keep, inv = _keep_mask(eff, rows, d, p, dev) if p > 0 else (torch.ones(rows, d, device=dev), 1.0)
-    y0 = torch.empty(rows, d, device=dev, dtype=torch.float16)
-    m0, r0 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-    ops.layernorm_fwd(x, g, b, y0, m0, r0, rows, d)
-    ldu = n_out + 8
-    u0 = torch.full((rows, ldu), float("nan"), device=dev, dtype=torch.float16)
-    ops.gemm(A=y0, am=ops.rowmap(d), K=d, B=A, ldb=d, M=rows, N=n_out, C16=u0, c16m=ops.rowmap(ldu),
-             flags=ops.NS_GEMM_DROP_A if p > 0 else 0, alpha=inv, drop_p=p, drop_seed=seed, seed_dev=ctr if p > 0 else None)
-    assert ops.layernorm_fwd_lora_supported(rows, d, n_out)
-    y1 = torch.empty_like(y0)
-    m1, r1 = torch.empty_like(m0), torch.empty_like(r0)
-    u1 = torch.full((rows, ldu), float("nan"), device=dev, dtype=torch.float16)
-    ops.layernorm_fwd_lora(x, g, b, y1, m1, r1, rows, d, A, d, n_out, u1, ldu, alpha=inv, drop_p=p, drop_seed=seed,
-                           seed_dev=ctr if p > 0 else None)
-    assert torch.equal(y1, y0) and torch.equal(m1, m0) and torch.equal(r1, r0)
-    assert torch.isnan(u1[:, n_out:].float()).all() and not torch.isnan(u1[:, :n_out].float()).any()
-    ref = (y0.float() * keep * inv) @ A.float().T
-    close(u1[:, :n_out].float(), ref, 1e-2, 5e-3, "fused down-projection vs torch")
-    if rows >= 8192:       # the streaming kernel's shapes: the same products in the same order
-        assert torch.equal(u1[:, :n_out], u0[:, :n_out])
-    else:
-        close(u1[:, :n_out].float(), u0[:, :n_out].float(), 4e-3, 2e-3, "fused vs tile kernel")
-
-
 # --------------------------------------------------------------------------- byte movers
 @pytest.mark.parametrize("pad", [8, 64])
 @pytest.mark.parametrize("ch,T", [(208, 6000), (273, 6000), (10, 100), (20, 402), (70, 130)])
@@ -990,10 +951,9 @@ def test_gemm_nt_split_k_into_fp32(ops, dev, M, N, K, splits):
     close(C, ref, 2e-3, 2e-3, "split-K NT")
 
 
-@pytest.mark.parametrize("form", ["p8s", "p4"])
+@pytest.mark.parametrize("form", ["p8s"])
 def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev, form):
-    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 700 tiles) and ns_gemm_p4 (128 x 256 tiles, two
-    workgroups per CU: csrc/ns_gemm_p4.hip) against ns_gemm_p8 (one tile per
+    """ns_gemm_p8s (one workgroup per CU walks several 256 x 256 tiles; the default at >= 700 tiles) against ns_gemm_p8 (one tile per
     workgroup) on ragged shapes with > 256 tiles, so that workgroups really carry the next tile's prologue through an epilogue:
     every epilogue kind, second product (ragged column groups, LoRA dropout), segmented row maps with an in-place residual, the
     GELU side product.  Same arithmetic in the same order: outputs must be bit-identical."""
@@ -1054,18 +1014,12 @@ def test_persistent_gemm_is_bitwise_the_one_tile_form(ops, dev, form):
         out["gelu_side"] = (Cs, Gs, slab)
         return out
     try:
-        lib.load().ns_debug_set_p4(0)
         lib.load().ns_debug_set_ring(4)
         ref = run()
-        if form == "p8s":
-            lib.load().ns_debug_set_ring(9)
-        else:
-            lib.load().ns_debug_set_ring(1)
-            lib.load().ns_debug_set_p4(127)
+        lib.load().ns_debug_set_ring(9)
         got = run()
     finally:
         lib.load().ns_debug_set_ring(1)
-        lib.load().ns_debug_set_p4(-1)
     for k in ref:
         for a, b in zip(got[k], ref[k]):
             assert not torch.isnan(a.float()).any(), k

@@ -28,8 +28,5 @@ for M in (128, 256, 640, 1024):
         L.ns_debug_set_ring(mode)
         row.append((mode, t(lambda: ops.gemm(A=A, am=rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=C, c16m=rowmap(N)))))
     L.ns_debug_set_ring(1)
-    L.ns_debug_set_p4(127)      # the 128 x 256 two-workgroups-per-CU kernel (csrc/ns_gemm_p4.hip) where ns_gemm takes the 256^2 one
-    row.append(("p4", t(lambda: ops.gemm(A=A, am=rowmap(K), K=K, B=B, ldb=K, M=M, N=N, C16=C, c16m=rowmap(N)))))
-    L.ns_debug_set_p4(0)
     byts = N * K * 2 + M * N * 2
     print(f"M={M:5d} " + "  ".join(f"{m if isinstance(m, str) else 'mode' + str(m)}: {ms*1e3:6.1f}us" for m, ms in row) + f"   HBM floor {byts/5.3e6:.1f}us", flush=True)
