@@ -56,6 +56,8 @@ def build_parser():
     add_arg("num_beams", type=int, default=5, help="beam width (reference: 5)")
     add_arg("max_new_tokens", type=int, default=None, help="cap on generated tokens")
     add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack)")
+    add_arg("feed_cache_dir", type=str, default="", help="with --device_feed: narrow-type cache of the kept channel rows (neuspeech1_amd/feed.py)")
+    add_arg("feed_cache_dtype", type=str, default="f16", help="f16 | f32 (see --feed_cache_dir)")
     add_arg("sequence_bias_type", type=str, default="phrase_word", choices=["word", "phrase", "phrase_word"],
             help="what --add_sequence_bias extracts from the training sentences (reference: phrase_word, needs yake)")
     return parser
@@ -136,7 +138,8 @@ def main(argv=None):
         from neuspeech1_amd.feed import SignalFeed
         dims = model.engine().dims
         test_dataset.raw_signals = True
-        feed = SignalFeed(model.device, dims.ch, dims.T, dims.ch_pad, threads=max(2, args.num_workers))
+        feed = SignalFeed(model.device, dims.ch, dims.T, dims.ch_pad, threads=max(2, args.num_workers),
+                          cache_dir=args.feed_cache_dir or None, cache_dtype=args.feed_cache_dtype)
 
     def batches():
         """(input, labels) with the NEXT batch's file reads already running on the feed's loader thread"""
@@ -204,6 +207,8 @@ def main(argv=None):
     dt = time.time() - t0
     if feed is not None:
         feed.close()        # its loader / reader threads end here, not whenever the collector finds the feed
+    if hasattr(model, "release_decode_sessions"):
+        model.release_decode_sessions()     # the loop is over: the sessions' caches / graphs (tens of GB at large-v2) go back to the allocator
     if world > 1:
         parts = [None] * world
         dist.all_gather_object(parts, (preds, refs, n_new, n_match, n_lab, dt, t_gen))

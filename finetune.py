@@ -79,6 +79,9 @@ def build_parser():
     add_arg("max_steps", type=int, default=-1, help="stop after N optimizer steps (smoke runs)")
     add_arg("device_feed", type=bool, default=True, help="slice / pad / cast the recordings on the GPU (ns_feed_pack) "
                                                         "instead of in the data-loader workers")
+    add_arg("feed_cache_dir", type=str, default="", help="with --device_feed: keep the kept channel rows of every recording in this directory, "
+            "rounded once to --feed_cache_dtype (bit-identical batches, a quarter / half of the float64 bytes read and staged per step)")
+    add_arg("feed_cache_dtype", type=str, default="f16", help="f16 | f32 (see --feed_cache_dir)")
     return parser
 
 
@@ -330,7 +333,8 @@ def main(argv=None):
     feed = None
     if train_dataset.raw_signals:
         from neuspeech1_amd.feed import SignalFeed
-        feed = SignalFeed(whisper.device, eng.dims.ch, eng.dims.T, eng.dims.ch_pad, threads=max(2, args.num_workers))
+        feed = SignalFeed(whisper.device, eng.dims.ch, eng.dims.T, eng.dims.ch_pad, threads=max(2, args.num_workers),
+                          cache_dir=args.feed_cache_dir or None, cache_dtype=args.feed_cache_dtype)
 
     step, eval_history, t_log, n_log = 0, [], time.time(), 0
     log_path = os.path.join(output_dir, "train_log.jsonl")

@@ -9,6 +9,14 @@ pread calls, no numpy temporaries), copied to HBM on a copy stream, and ONE kern
 collator rule while it transposes into the (B, T+2, Cp) fp16 layout the conv GEMM reads.  Bit-identical to
 collator -> ns_signal_pack (tests/test_feed_gpu.py).
 
+Round 6: an OPT-IN cache of the kept channel rows in a narrower type (`SignalFeed(cache_dir=..., cache_dtype="f16" |
+"f32")`, finetune.py / evaluation.py --feed_cache_dir / --feed_cache_dtype).  The reference's recordings are float64; what reaches the
+first conv is round16(round32(x)) (collator: torch float32; autocast: fp16), which is exactly what ns_feed_pack computes from the float64
+bytes.  The cache stores those roundings once per (file, channel slice) -- numpy's astype is round-to-nearest-even like the device's
+conversions, so a cached batch is BIT-IDENTICAL to the float64 one (tests/test_feed_gpu.py) -- and from then on a rank reads and stages a
+quarter (f16) or half (f32) of the bytes: at eight ranks x ~2 100 samples/s the float64 files are ~180 GB/s through host DRAM and eight
+PCIe links, the f16 cache 45 GB/s.  f16 cannot reproduce the optional fp32 copy of the batch (keep_x32): such feeds cache f32.
+
 Host objects:
   RawSignal     what utils.reader.CustomDataset(raw_signals=True) returns instead of the padded array
   plan_read     header-only planning of one recording (CPU-testable)
@@ -97,6 +105,57 @@ def plan_read(raw: RawSignal, T: int) -> ReadPlan:
         arr = np.ascontiguousarray(arr.astype(np.float32))
     code, isz = _DTYPES["<f" + str(arr.dtype.itemsize)]
     return ReadPlan("array", raw.path, rows, arr.shape[1], arr.shape[1], code, isz, arr.nbytes, array=arr)
+
+
+# ---------------------------------------------------------------------------------------------------- narrow-type cache of the kept rows
+_CACHE_NP = {"f16": np.float16, "f32": np.float32}
+_NPY_HDR = 128      # cache files: .npy version 1 with the header padded to 128 bytes (data 64-B aligned)
+
+
+def cache_path(cache_dir: str, raw: RawSignal, T: int, dtype: str) -> str:
+    """One cache file per (source file identity, channel slice, crop rule, type).  The source's size and mtime are part of the name: a
+    rewritten recording gets a new cache file instead of serving stale rows."""
+    import hashlib
+    st = os.stat(raw.path)
+    key = f"{os.path.abspath(raw.path)}|{st.st_size}|{st.st_mtime_ns}|{raw.row0}|{raw.row1}|{T}|{dtype}"
+    return os.path.join(cache_dir, hashlib.sha256(key.encode()).hexdigest()[:32] + f".{dtype}.npy")
+
+
+def build_cache_file(plan: ReadPlan, dst: str, dtype: str):
+    """The rows a plan would stage, rounded as collator + autocast round them (float64 -> float32 [-> float16], round-to-nearest-even at
+    each step: what ns_feed_pack does on the device), written as a C-order .npy next to its final name and renamed into place (readers
+    never see a partial file; two ranks racing write the same bytes)."""
+    buf = bytearray(plan.nbytes)
+    _fill(plan, memoryview(buf))
+    src = np.frombuffer(buf, dtype={NS_FEED_F64: "<f8", NS_FEED_F32: "<f4", NS_FEED_F16: "<f2"}[plan.dtype]).reshape(plan.rows, plan.n)
+    out = src.astype(np.float32)            # the collator's torch.tensor(x, dtype=float32)
+    if dtype == "f16":
+        out = out.astype(np.float16)        # autocast's cast in front of the first conv
+    hdr = ("{'descr': '%s', 'fortran_order': False, 'shape': (%d, %d), }" % ("<f2" if dtype == "f16" else "<f4", plan.rows, plan.n)).encode("latin1")
+    pad = _NPY_HDR - 10 - len(hdr) - 1
+    assert pad >= 0
+    head = b"\x93NUMPY\x01\x00" + struct.pack("<H", _NPY_HDR - 10) + hdr + b" " * pad + b"\n"
+    tmp = f"{dst}.tmp.{os.getpid()}.{id(buf)}"
+    with open(tmp, "wb") as f:
+        f.write(head)
+        f.write(np.ascontiguousarray(out).tobytes())
+    os.replace(tmp, dst)
+
+
+def plan_cached(raw: RawSignal, T: int, cache_dir: str, dtype: str) -> ReadPlan:
+    """plan_read through the cache: the plan of the cached rows (one contiguous span of f16 / f32), building the file on first touch.
+    Recordings the plain plan would hand to numpy ('array': exotic dtypes / byte orders) and empty slices are not cached."""
+    cp = cache_path(cache_dir, raw, T, dtype)
+    if not os.path.exists(cp):
+        plan = plan_read(raw, T)
+        if plan.kind == "array" or plan.nbytes == 0 or (plan.dtype == NS_FEED_F16) or (plan.dtype == NS_FEED_F32 and dtype == "f32"):
+            return plan                      # nothing narrower to store
+        os.makedirs(cache_dir, exist_ok=True)
+        build_cache_file(plan, cp, dtype)
+    off, shape, descr, fortran = npy_layout(cp)
+    code, isz = _DTYPES[descr]
+    rows, n = shape
+    return ReadPlan("span", cp, rows, n, n, code, isz, rows * n * isz, off)
 
 
 def _pread_into(fd: int, view: memoryview, offset: int):
@@ -210,9 +269,17 @@ class SignalFeed:
     MAX_SLOTS = 8
     MIN_SLOTS = 3
 
-    def __init__(self, device, ch: int, T: int, Cp: int, threads: int = 8, keep_x32: bool = False):
+    def __init__(self, device, ch: int, T: int, Cp: int, threads: int = 8, keep_x32: bool = False, cache_dir: Optional[str] = None,
+                 cache_dtype: str = "f16"):
         self.device, self.ch, self.T, self.Cp, self.keep_x32 = torch.device(device), ch, T, Cp, keep_x32
         assert self.device.type == "cuda", "SignalFeed drives the HIP path; there is no host fallback"
+        if cache_dir:
+            if cache_dtype not in _CACHE_NP:
+                raise ValueError(f"feed cache type {cache_dtype!r}: 'f16' or 'f32'")
+            if keep_x32 and cache_dtype == "f16":
+                cache_dtype = "f32"         # the fp32 copy of the batch is round32(x): an f16 cache could not reproduce it
+        self.cache_dir, self.cache_dtype = (cache_dir or None), cache_dtype
+        self.cache_built = 0
         self.stream = torch.cuda.Stream(self.device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self.slots: List[_Slot] = []
@@ -259,7 +326,10 @@ class SignalFeed:
         assert B > 0
         for r in raws:
             assert r.ch == self.ch, f"recording planned for {r.ch} channels, feed built for {self.ch}"
-        plans = list(self.pool.map(lambda r: plan_read(r, self.T), raws))
+        if self.cache_dir:
+            plans = list(self.pool.map(lambda r: plan_cached(r, self.T, self.cache_dir, self.cache_dtype), raws))
+        else:
+            plans = list(self.pool.map(lambda r: plan_read(r, self.T), raws))
         offs, used = layout_batch(plans)
         s = self._slot()
         with GPU_CAPTURE_LOCK:              # never synchronize / allocate while another thread has a graph capture open

@@ -91,6 +91,8 @@ class Generator:
         self.max_sessions = 2
         self.max_session_frac = 0.25      # of the device memory, all sessions together (large-v2 at B = 128, beam 5: 62 GB of cross K|V images each)
         self._sessions = collections.OrderedDict()
+        self.capture_failures = 0           # hipGraph captures that were invalidated (one disables graphs for this Generator)
+        self._graph_graveyard = []          # graph objects of a capture that did not end cleanly: never destroyed (see run_loop.build)
 
     def clear_sessions(self):
         """release the device state, launch lists and hipGraphs kept for the call signatures seen so far"""
@@ -109,7 +111,28 @@ class Generator:
         return hash(tuple(ptrs))
 
     @torch.no_grad()
-    def generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
+    def generate(self, x32: torch.Tensor, prompt: torch.Tensor, **kw) -> torch.Tensor:
+        """see _generate.  NS_LISTS_VERIFY=1 (debug): whenever the loop replayed recorded launch lists, the same call is run
+        again with eager launches only and the ids compared -- a torch op that slipped into a recorded region (it would run once, at
+        record time, and be missing from every replay) or a list that outlived a buffer shows up as a difference here"""
+        out = self._generate(x32, prompt, **kw)
+        import os
+        if os.environ.get("NS_LISTS_VERIFY") == "1" and str(self.last_loop_mode).startswith("lists") and kw.get("trace") is None:
+            mode = self.last_loop_mode
+            saved = (self.use_lists, self.use_graph, self.cache_sessions)
+            self.use_lists = self.use_graph = self.cache_sessions = False
+            try:
+                ref = self._generate(x32, prompt, **kw)
+            finally:
+                self.use_lists, self.use_graph, self.cache_sessions = saved
+            self.last_loop_mode = mode
+            if not torch.equal(ref, out):
+                bad = (ref != out).any(dim=1).nonzero().flatten().tolist()
+                raise RuntimeError(f"NS_LISTS_VERIFY: replayed launch lists ({mode}) and eager launches disagree on rows {bad[:8]}")
+        return out
+
+    @torch.no_grad()
+    def _generate(self, x32: torch.Tensor, prompt: torch.Tensor, num_beams: int = 1, max_new_tokens: int = 64,
                  repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0, suppress_tokens=(),
                  begin_suppress_tokens=(), length_penalty: float = 1.0, eos_id: int | None = None,
                  pad_id: int | None = None, check_every: int = 4, sequence_bias=None, forced_decoder_ids=None,
@@ -307,7 +330,7 @@ class Generator:
         def run_loop(select, ping_pong):
             """select(cur, ctr) picks token `cur` from `logits` (and reverses the lists in `ping_pong`); the step then
             feeds it at position `cur`.  First iteration eager (lazy kernel attributes / workspaces), then graphs."""
-            nonlocal cur
+            nonlocal cur, graph_ok
             n_sel = 0
             ctr = None
             graphs = None
@@ -324,25 +347,52 @@ class Generator:
             def build(as_list):
                 """the two (select, feed) pairs -- one per ping-pong parity -- as launch lists or as hipGraphs.  Nothing is launched;
                 the host-side lists end in the orientation they started in (two reversals)."""
+                nonlocal graph_ok
                 pairs = []
                 torch.cuda.synchronize()
-                for _ in range(2):
-                    if as_list:
-                        gs, gt = ops.LaunchList(), ops.LaunchList()
-                        with ops.recording(gs):
-                            select(cur, ctr)
-                        with ops.recording(gt):
-                            feed()
-                    else:
-                        gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                        # thread-local capture mode + the package's capture lock: other host threads (the data feed's
-                        # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
-                        with GPU_CAPTURE_LOCK:
-                            with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                # select() / step() reverse host-side ping-pong lists as they go: a capture that dies half way must leave them as they were
+                snap = [(l_, list(l_)) for l_ in (anc, h, *ping_pong)]
+                prev_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
+                gs = gt = None
+                try:
+                    for _ in range(2):
+                        if as_list:
+                            gs, gt = ops.LaunchList(), ops.LaunchList()
+                            gs.keep = gt.keep = ws       # the session's tensors are what the recorded raw addresses point into
+                            with ops.recording(gs):
                                 select(cur, ctr)
-                            with torch.cuda.graph(gt, capture_error_mode="thread_local"):
+                            with ops.recording(gt):
                                 feed()
-                    pairs.append((gs, gt))
+                        else:
+                            gs, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                            # thread-local capture mode + the package's capture lock: other host threads (the data feed's
+                            # loader thread synchronizes, allocates and copies on its own stream) must not invalidate this
+                            with GPU_CAPTURE_LOCK:
+                                with torch.cuda.graph(gs, capture_error_mode="thread_local"):
+                                    select(cur, ctr)
+                                with torch.cuda.graph(gt, capture_error_mode="thread_local"):
+                                    feed()
+                        pairs.append((gs, gt))
+                except RuntimeError as e:
+                    if as_list:
+                        raise
+                    # A host thread outside GPU_CAPTURE_LOCK can invalidate a capture on HIP (ADVICE r5; the rule of engine.train_step):
+                    # nothing has executed.  torch.cuda.graph.__exit__ leaves its capture stream current when capture_end raises -- put
+                    # the caller's back --, the half-built graph objects are never destroyed (their destructor has aborted the process
+                    # on this stack), the session forgets its graphs, and ONE failure ends graph use for this Generator: the loop goes
+                    # on with launch lists or eager launches.
+                    torch.cuda.synchronize()
+                    torch.cuda.set_stream(prev_stream)
+                    for l_, saved in snap:
+                        l_[:] = saved
+                    self._graph_graveyard.append((pairs, gs, gt))
+                    self.capture_failures += 1
+                    self.use_graph = graph_ok = False
+                    ws["graphs"] = None
+                    import warnings
+                    warnings.warn(f"generate: hipGraph capture failed ({str(e).splitlines()[0][:120]}); launch lists / eager launches from "
+                                  "here on (graphs disabled for this Generator)")
+                    return None
                 return pairs
 
             def replay(g):
@@ -376,11 +426,12 @@ class Generator:
                         if chunk_t0 is not None and chunk_steps == check_every:
                             slow_chunks = slow_chunks + 1 if enq > self.adaptive_frac * (now - chunk_t0) else 0
                             if slow_chunks >= 2 and graph_ok and self.adaptive and max_len - cur >= self.adaptive_min_steps:
-                                graphs = build(False)
-                                is_list = False
-                                self.last_loop_mode = f"lists->graphs@{cur - P}"
-                                if key is not None:
-                                    ws["graphs"] = graphs
+                                g_new = build(False)
+                                if g_new is not None:       # (a failed capture: the lists go on)
+                                    graphs, is_list = g_new, False
+                                    self.last_loop_mode = f"lists->graphs@{cur - P}"
+                                    if key is not None:
+                                        ws["graphs"] = graphs
                         enq, chunk_t0, chunk_steps = 0.0, time.perf_counter(), 0
                 if graphs is None:
                     step(next_tok, cur - 1, parent)
@@ -405,12 +456,14 @@ class Generator:
                         if cached_graphs:
                             graphs, is_list = ws["graphs"], False
                             self.last_loop_mode = "graphs (session)"
-                        elif as_graph:
-                            graphs, is_list = build(False), False
+                        elif as_graph and (g_new := build(False)) is not None:
+                            graphs, is_list = g_new, False
                             self.last_loop_mode = "graphs"
                             if key is not None:
                                 ws["graphs"] = graphs
-                        elif ws["lists"] is not None and as_list:
+                        elif not (as_list or (as_graph and self.use_lists and trace is None and max_len - cur >= 4)):
+                            pass        # (the capture failed and lists are not an option here: eager launches)
+                        elif ws["lists"] is not None:
                             graphs, is_list = ws["lists"], True
                             self.last_loop_mode = "lists (session)"
                         else:

@@ -38,10 +38,16 @@ _tls = _threading.local()
 
 
 class LaunchList:
-    __slots__ = ("calls",)
+    """Entries hold RAW device addresses (the marshalled ctypes arguments), exactly as a captured hipGraph does: `keep` is where the
+    recorder parks whatever owns that memory (generate.py: the decode session whose tensors the launches point into), so a list can
+    never outlive its buffers.  Only entry points that go through _call() are recorded: a torch op issued inside a recorded region runs
+    once, at record time, and is absent from every replay -- NS_LISTS_VERIFY=1 makes generate() check a freshly recorded list against
+    eager launches (tests/test_generate_gpu.py)."""
+    __slots__ = ("calls", "keep")
 
     def __init__(self):
         self.calls = []
+        self.keep = None
 
     def replay(self):
         st = _stream()
@@ -207,8 +213,11 @@ def gemm(**kw):
     GEMM_PROFILE.append((kind, fl, e0, e1, by))
 
 
-def gemm_ln_supported(M: int, N: int, K: int, K2: int = 0) -> bool:
-    return bool(L.load().ns_gemm_ln_supported(M, N, K, K2))
+def gemm_ln_supported(M: int, N: int, K: int, K2: int = 0, lda: int | None = None) -> bool:
+    """the shape test of the library AND ns_gemm_ln's operand-extent test (32-bit buffer offsets: the last row of A, row stride lda, must
+    end below 2 GiB -- e.g. fc2 of a very large batch), so that a caller falls back to ns_gemm + ns_layernorm_fwd instead of raising"""
+    lda = K if lda is None else lda
+    return bool(L.load().ns_gemm_ln_supported(M, N, K, K2)) and 2 * ((M - 1) * lda + K + 64) < 0x7FFF0000
 
 
 def gemm_ln(*, gamma, beta, x16, ldx, mean=None, rstd=None, eps=1e-5, **kw):

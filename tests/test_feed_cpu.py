@@ -116,6 +116,13 @@ def test_loader_workers_come_from_a_forkserver_and_do_not_reimport_the_callers_s
             fork_safe_iter(torch.utils.data.DataLoader(ds, batch_size=4, num_workers=2, collate_fn=coll))
         except RuntimeError as e:
             print("REFUSED", str(e)[:40], flush=True)
+        def my_collate(batch):       # defined in the main script: a worker that does not re-import it cannot unpickle this
+            return coll(batch)
+        try:
+            fork_safe_iter(torch.utils.data.DataLoader(ds_raw, batch_size=4, num_workers=2, collate_fn=my_collate,
+                                                       multiprocessing_context=worker_context(2)))
+        except RuntimeError as e:
+            print("LOCAL", "collate_fn (my_collate)" in str(e) and "importable module" in str(e), flush=True)
         print("FILE", __file__ is not None, flush=True)
     """))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
@@ -123,3 +130,4 @@ def test_loader_workers_come_from_a_forkserver_and_do_not_reimport_the_callers_s
     out = r.stdout
     assert out.count("MAIN BODY RUNS") == 1, out
     assert "EPOCH 0 10" in out and "EPOCH 1 10" in out and "REFUSED DataLoader workers must come from" in out and "FILE True" in out, out
+    assert "LOCAL True" in out, out      # objects defined in the main script are named up front, not by a pickling error inside a worker

@@ -45,6 +45,70 @@ def test_feed_pack_is_bit_identical_to_collator_plus_signal_pack(dev, tmp_path, 
     feed.close()
 
 
+@pytest.mark.parametrize("modal_ch,cache_dtype", [(208, "f16"), (208, "f32"), (273, "f16")])
+def test_cached_feed_is_bit_identical_and_stages_a_fraction_of_the_bytes(dev, tmp_path, modal_ch, cache_dtype):
+    """SignalFeed(cache_dir=...) (round 6): the kept channel rows of every recording are rounded ONCE on the host exactly as collator +
+    autocast round them (float64 -> float32 [-> float16]) and read from the cache afterwards.  The packed fp16 batch must be bit for bit
+    the float64 path's -- every reader case of tests/feed_cases.py: short and long recordings, channel padding, crops, float32 and
+    exotic-dtype files -- on the cache-building pass and on the cache-reading pass, with a quarter / half of the float64 bytes staged;
+    a feed that also hands out the fp32 batch (keep_x32) falls back to an f32 cache and stays exact there too."""
+    import os
+    from neuspeech1_amd import ops
+    from neuspeech1_amd.feed import SignalFeed
+    proc = SyntheticProcessor(WHISPER_BASE)
+    jl = write_cases(str(tmp_path), modal_ch)
+    ds, ds_raw = datasets(jl, proc, modal_ch)
+    coll = DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+    ref = coll([ds[i] for i in range(len(ds))])
+    raws = coll([ds_raw[i] for i in range(len(ds_raw))])["input_features"]
+    B, T, Cp = len(raws), 6000, (modal_ch + 15) // 16 * 16
+    x32 = ref["input_features"].to(dev)
+    want = torch.full((B, T + 2, Cp), 7.0, dtype=torch.float16, device=dev)
+    ops.signal_pack(x32, want, B, modal_ch, T, Cp)
+    plain = SignalFeed(dev, modal_ch, T, Cp, threads=4)
+    ps = plain.load(raws).acquire()
+    torch.cuda.synchronize()
+    assert torch.equal(ps.xin, want)
+    ps.release()
+    plain_bytes = plain.bytes_staged
+    plain.close()
+    cdir = str(tmp_path / "cache")
+    staged = []
+    for rep in range(2):             # pass 0 builds the cache files, pass 1 (a NEW feed: another rank, another epoch) only reads them
+        feed = SignalFeed(dev, modal_ch, T, Cp, threads=4, cache_dir=cdir, cache_dtype=cache_dtype)
+        ps = feed.load(raws).acquire()
+        torch.cuda.synchronize()
+        assert torch.equal(ps.xin, want), rep
+        ps.release()
+        staged.append(feed.bytes_staged)
+        feed.close()
+    files = os.listdir(cdir)
+    assert files and all(f.endswith(f".{cache_dtype}.npy") for f in files) and not any(".tmp." in f for f in files)
+    # (the case list holds float32 / float16 / host-fallback files too: a pure float64 set stages exactly 1/4 and 1/2)
+    assert staged[0] == staged[1] < plain_bytes * (0.5 if cache_dtype == "f16" else 0.75), (staged, plain_bytes)
+    # the fp32 copy of the batch is round32(x): a feed that keeps it caches f32 whatever was asked for
+    feed = SignalFeed(dev, modal_ch, T, Cp, threads=4, keep_x32=True, cache_dir=str(tmp_path / "cache32"), cache_dtype=cache_dtype)
+    assert feed.cache_dtype == "f32"
+    for rep in range(2):
+        ps = feed.load(raws).acquire()
+        torch.cuda.synchronize()
+        assert torch.equal(ps.xin, want) and torch.equal(ps.x32, x32)
+        ps.release()
+    feed.close()
+    # a rewritten recording must not be served from its old cache file
+    first = raws[0]
+    arr = np.load(first.path)
+    np.save(first.path, arr * 0.5)
+    os.utime(first.path, ns=(os.stat(first.path).st_atime_ns, os.stat(first.path).st_mtime_ns + 1_000_000))
+    feed = SignalFeed(dev, modal_ch, T, Cp, threads=2, cache_dir=cdir, cache_dtype=cache_dtype)
+    ps = feed.load([first]).acquire()
+    ref2 = SignalFeed(dev, modal_ch, T, Cp, threads=2)
+    ps2 = ref2.load([first]).acquire()
+    torch.cuda.synchronize()
+    assert torch.equal(ps.xin, ps2.xin) and not torch.equal(ps.xin, want[:1])
+    feed.close(); ref2.close()
+
+
 def test_training_step_from_the_feed_matches_the_tensor_path(dev, tmp_path):
     from neuspeech1_amd.engine import LoraSpec, MegWhisperEngine, TrainCfg
     from neuspeech1_amd.feed import RawSignal, SignalFeed

@@ -176,6 +176,64 @@ def test_launch_lists_hand_over_to_graphs_when_the_host_is_the_bottleneck(setup,
 
 
 @pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
+def test_a_failed_graph_capture_falls_back_and_keeps_the_ids(setup, monkeypatch, nb, kw):
+    """a hipGraph capture of the decode loop that is invalidated (a host thread outside the capture lock) must not abort the
+    evaluation run.  Simulated: the second capture_end of the build raises AFTER ending the capture, which is what torch does -- and
+    what leaves the capture stream current.  The generation goes on (launch lists here), ids are the eager loop's, the caller's stream is
+    back, the host-side ping-pong lists are where they were (a beam search that continued on swapped lists would give other ids), graphs
+    are off for this Generator from then on, and its session holds no half-built graphs."""
+    from neuspeech1_amd.generate import Generator
+    g, dims, gen, x, prompt = setup
+    kw = dict(kw, suppress_tokens=(dims.eos_id,))
+    eager = Generator(gen.eng, use_graph=False)
+    eager.use_lists = False
+    ref = eager.generate(x, prompt, num_beams=nb, max_new_tokens=30, **kw)
+    real, calls = torch.cuda.CUDAGraph.capture_end, {"n": 0}
+
+    def capture_end(self):
+        real(self)
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("simulated: operation failed due to a previous error during capture")
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_end", capture_end)
+    g2 = Generator(gen.eng, use_graph=True, graph_min_steps=0)
+    before = torch.cuda.current_stream()
+    with pytest.warns(UserWarning, match="capture failed"):
+        out = g2.generate(x, prompt, num_beams=nb, max_new_tokens=30, **kw)
+    assert torch.cuda.current_stream() == before
+    assert g2.capture_failures == 1 and g2.use_graph is False and g2.last_loop_mode == "lists", g2.last_loop_mode
+    assert torch.equal(out, ref)
+    assert all(w["graphs"] is None for w in g2._sessions.values())
+    out = g2.generate(x, prompt, num_beams=nb, max_new_tokens=30, **kw)       # later calls of the signature: the lists, no new capture
+    assert calls["n"] == 2 and g2.last_loop_mode == "lists (session)" and torch.equal(out, ref)
+
+
+def test_lists_verify_mode_checks_replayed_lists_against_eager_launches(setup, monkeypatch):
+    """NS_LISTS_VERIFY=1 (debug): a generation that replayed launch lists is repeated with eager launches and compared.  Here it must pass;
+    a launch dropped from the recorded list (what a torch op inside a recorded region amounts to) must be caught."""
+    from neuspeech1_amd import ops
+    from neuspeech1_amd.generate import Generator
+    g, dims, gen, x, prompt = setup
+    monkeypatch.setenv("NS_LISTS_VERIFY", "1")
+    kw = dict(num_beams=5, max_new_tokens=20, repetition_penalty=5.0, no_repeat_ngram_size=2, suppress_tokens=(dims.eos_id,))
+    g2 = Generator(gen.eng, use_graph=False)
+    g2.generate(x, prompt, **kw)
+    assert g2.last_loop_mode == "lists"
+    real = ops.LaunchList.replay
+
+    def lossy(self):          # drops the list's last launch
+        saved, self.calls = self.calls, self.calls[:-1]
+        try:
+            real(self)
+        finally:
+            self.calls = saved
+    monkeypatch.setattr(ops.LaunchList, "replay", lossy)
+    g3 = Generator(gen.eng, use_graph=False)
+    with pytest.raises(RuntimeError, match="NS_LISTS_VERIFY"):
+        g3.generate(x, prompt, **kw)
+
+
+@pytest.mark.parametrize("nb,kw", [(1, {}), (5, dict(repetition_penalty=5.0, no_repeat_ngram_size=2))])
 def test_decode_sessions_replay_across_calls(setup, dev, nb, kw):
     """A Generator keeps the device state and the recorded / captured loop of a call signature (an evaluation run: one signature for
     every batch): call 1 records launch lists, call 2 captures the hipGraphs, call 3 replays them from its first loop step -- on

@@ -34,7 +34,8 @@ def main():
         import subprocess
         merged = {}
         with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
-            for leg in ("host_path_1proc", f"host_path_{args.workers}workers", "gpu_feed", "train_host_path", "train_gpu_feed"):
+            for leg in ("host_path_1proc", f"host_path_{args.workers}workers", "gpu_feed", "gpu_feed_cache_f32", "gpu_feed_cache_f16",
+                        "train_host_path", "train_gpu_feed", "train_gpu_feed_cache_f16"):
                 cmd = [sys.executable, os.path.abspath(__file__), "--only", leg, "--data-dir", tmp, "--batch", str(args.batch),
                        "--ch", str(args.ch), "--n", str(args.n), "--steps", str(args.steps), "--workers", str(args.workers),
                        "--files", str(args.files)]
@@ -89,10 +90,18 @@ def main():
 
         # 1. producer rates alone (no training): host collator path, 0 and W workers; feed path
         for name, raw, w in (("host_path_1proc", False, 0), (f"host_path_{args.workers}workers", False, args.workers),
-                             ("gpu_feed", True, 0)):
+                             ("gpu_feed", True, 0), ("gpu_feed_cache_f32", True, 0), ("gpu_feed_cache_f16", True, 0)):
             if args.only and name not in args.only.split(","):
                 continue
-            feed = SignalFeed(dev, dims.ch, dims.T, dims.ch_pad, threads=args.workers) if raw else None
+            cdt = name.rsplit("_", 1)[1] if "cache" in name else None
+            feed = SignalFeed(dev, dims.ch, dims.T, dims.ch_pad, threads=args.workers,
+                              cache_dir=os.path.join(tmp, "cache_" + cdt) if cdt else None, cache_dtype=cdt or "f16") if raw else None
+            if cdt:     # build the cache outside the timed region (first touch of every file): the steady state is what a run sees
+                from neuspeech1_amd.feed import RawSignal, plan_cached
+                t0 = time.perf_counter()
+                for r in rows:
+                    plan_cached(RawSignal(r["eeg"]["path"], 0, args.ch, args.ch), dims.T, feed.cache_dir, cdt)
+                out[name + "_build_s"] = round(time.perf_counter() - t0, 2)
             it = iter(DevicePrefetcher(loader(raw, w, 4 if (w == 0 and not raw) else None), dev, feed))
             for _ in range(3):
                 x, _y = next(it)
@@ -110,7 +119,8 @@ def main():
             out[name + "_batches_per_s"] = round(k / dt, 2)
             out[name + "_samples_per_s"] = round(k * args.batch / dt, 1)
             if raw:
-                out["gpu_feed_staged_MB_per_batch"] = round(feed.bytes_staged / (k + 3) / 1e6, 1)
+                out[name + "_staged_MB_per_batch"] = round(feed.bytes_staged / (k + 3) / 1e6, 1)
+            if raw and not cdt:
                 # kernel alone: re-run ns_feed_pack on the last staged slot
                 s = feed.slots[0]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -125,16 +135,19 @@ def main():
                 byts = args.batch * (min(args.n, dims.T) * dims.ch * 8 + (dims.T + 2) * dims.ch_pad * 2)
                 out["feed_pack_ms"] = round(ms, 4)
                 out["feed_pack_GBps"] = round(byts / ms / 1e6, 1)
+            if raw:
                 feed.close()
 
         # 2. training fed from files, both ways
-        for name, raw in (("train_host_path", False), ("train_gpu_feed", True)):
+        for name, raw in (("train_host_path", False), ("train_gpu_feed", True), ("train_gpu_feed_cache_f16", True)):
             if args.only and name not in args.only.split(","):
                 continue
+            cdt = "f16" if "cache" in name else None
             torch.manual_seed(42)
             eng = MegWhisperEngine(dims, make_state_dict(dims, 42), lora=LoraSpec(r=32, alpha=64.0, dropout=0.05),
                                    train_cfg=TrainCfg(lr=1e-3, warmup_steps=500, total_steps=100000), device=dev)
-            feed = SignalFeed(dev, dims.ch, dims.T, dims.ch_pad, threads=args.workers) if raw else None
+            feed = SignalFeed(dev, dims.ch, dims.T, dims.ch_pad, threads=args.workers,
+                              cache_dir=os.path.join(tmp, "cache_" + cdt) if cdt else None, cache_dtype=cdt or "f16") if raw else None
             it = iter(DevicePrefetcher(loader(raw, args.workers), dev, feed))
             k = 0
             for x, y in it:

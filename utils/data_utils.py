@@ -148,13 +148,26 @@ class _main_not_reimported:
 def fork_safe_iter(loader):
     """iter(loader).  The one place the CLIs start their workers: a loader with workers must have been built with
     `multiprocessing_context=worker_context(n)` -- forking them from this (GPU-driving) process is refused -- and the children do not
-    re-import the caller's main script."""
+    re-import the caller's main script.  REQUIREMENT that follows: whatever the workers unpickle -- the dataset, the collate_fn, a
+    worker_init_fn, a batch sampler -- must be defined in an IMPORTABLE module (utils.reader / utils.data_utils are), not in the caller's
+    main script or notebook cell: a class whose __module__ is '__main__' cannot be found by a child that does not re-import the script.
+    Checked up front, so the failure is this message and not a pickling traceback inside a worker."""
     if getattr(loader, "num_workers", 0) > 0:
         ctx = getattr(loader, "multiprocessing_context", None)
         method = ctx.get_start_method() if ctx is not None else None
         if method not in ("forkserver", "spawn"):
             raise RuntimeError("DataLoader workers must come from utils.data_utils.worker_context() (forkserver), never from a fork "
                                f"of the process that holds the GPU (start method: {method or 'fork (default)'})")
+        local = []
+        for what in ("dataset", "collate_fn", "worker_init_fn", "batch_sampler", "sampler"):
+            obj = getattr(loader, what, None)
+            mod = getattr(obj, "__module__", None)      # functions and classes carry their own; an instance answers with its class's
+            if obj is not None and mod == "__main__":
+                local.append(f"{what} ({getattr(obj, '__qualname__', type(obj).__qualname__)})")
+        if local:
+            raise RuntimeError("DataLoader workers are started without re-importing the caller's main script, so they cannot unpickle objects "
+                               "defined in it: " + ", ".join(local) + ".  Move them into an importable module (as utils.reader.CustomDataset "
+                               "and utils.data_utils.DataCollatorBrainSpeechSeq2SeqWithPadding are), or use num_workers=0.")
         with _main_not_reimported():
             return iter(loader)
     return iter(loader)

@@ -257,6 +257,22 @@ class WhisperForConditionalGeneration(nn.Module):
     def invalidate_engine(self):
         """call after editing frozen weights in place"""
         self._engine = None
+        self.release_decode_sessions()
+
+    def release_decode_sessions(self):
+        """Free what generate() keeps between calls: the Generator of this model holds up to two decode SESSIONS (KV caches, cross K|V and
+        transposed-V images, recorded launch lists, hipGraph pools: up to a quarter of the device memory; ~62 GB each at large-v2, B = 128,
+        beam 5).  evaluation.py calls this when its loop ends; train() calls it when the model goes back to training; a caller that
+        evaluates and then trains, or loads a second model, in the same process gets the memory back."""
+        gen = getattr(self, "_generator", None)
+        if gen is not None:
+            gen.clear_sessions()
+        self._generator = None
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.release_decode_sessions()
+        return super().train(mode)
 
     def post_init(self):
         """random re-initialisation of every weight (what --random_initialize_whisper does through HF's post_init)"""
