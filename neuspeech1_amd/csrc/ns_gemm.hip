@@ -372,7 +372,10 @@ bool ns_gemm_skinny_ok(const ns_gemm_desc* d);
 #define NS_P8S_MIN_TILES 700
 #endif
 static int g_use_ring = 1;
-extern "C" void ns_debug_set_ring(int on) { g_use_ring = on; }
+// values >= 100 do not change the mode: they set a free-standing A/B flag (flag = value - 100) that probe builds of single kernels read
+// (tools/probe/*: two variants of one kernel timed in ONE process, cdna guide rule 24); the shipped kernels ignore it unless a comment says so
+int g_ns_ab_flag = 0;
+extern "C" void ns_debug_set_ring(int on) { if (on >= 100) g_ns_ab_flag = on - 100; else g_use_ring = on; }
 
 // the shapes the phase-interleaved 256 x 256 kernel takes in automatic mode, with whole 256-column tiles
 extern "C" int ns_gemm_side_supported(int M, int N, int K) {

@@ -14,11 +14,13 @@
 namespace {
 
 constexpr int BN = 128, BKS = 32, NTH = 256;     // BM = 128 or 64 (template): 64-row tiles when 128-row tiles leave most CUs idle
-// ring depth: 4 slices, one barrier per slice (the dropout variants, whose mask sits between two slices); 6 slices walked in PAIRS
-// otherwise -- one barrier, one counted wait and one batch of fragment reads per 64-deep pair: a slice of these mid-size launches is
-// 128 MFMA cycles behind ~600 cycles of wait + barrier + DMA issue + ds_read latency (880 cycles per slice measured at K = 2048), so
-// halving the number of synchronisation points is worth more than the third slice of look-ahead it costs (round 5)
-template <bool DROP> struct ring_depth { static constexpr int value = DROP ? 4 : 6; };
+// ring depth: 4 slices, one barrier per slice (the dropout variants, whose mask sits between two slices; the 128-row tile; 64-row launches
+// of >= 1024 workgroups), or 6 slices walked in PAIRS (64-row launches that leave a CU <= ~3 workgroups) -- one barrier, one counted wait
+// and one batch of fragment reads per 64-deep pair: a slice of these mid-size launches is 128 MFMA cycles behind ~600 cycles of wait +
+// barrier + DMA issue + ds_read latency (880 cycles per slice measured at K = 2048), so halving the number of synchronisation points is
+// worth more than the third slice of look-ahead it costs -- as long as the LDS it takes does not cost a resident workgroup that would
+// have had work (the rule and its measurements: ns_gemm_ring_launch)
+template <bool PAIRS> struct ring_depth { static constexpr int value = PAIRS ? 6 : 4; };
 constexpr int B_BYTES = BN * BKS * 2;          // 8 KiB: one B slice
 
 __device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -38,13 +40,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // K tails: chunks beyond the valid K range are fetched from a block of zeros, so the MFMA loop is branch-free
 __device__ __attribute__((aligned(16))) const uint32_t ns_zero_chunk128[4] = {0, 0, 0, 0};
 
-template <bool DROP, int BM>
+template <bool DROP, int BM, bool PAIRS>
 __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc p) {
+  static_assert(!(DROP && PAIRS), "the dropout mask sits between two single slices");
   constexpr int MI = BM / 64;                  // 32-row MFMA tiles per wave along M (wave grid 2 x 2: wave tile BM/2 x 64)
   constexpr int A_BYTES = BM * BKS * 2;        // one A slice: 8 or 4 KiB
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int AP = BM / 64;                  // 1-KiB A pieces per wave and slice (B: always 2)
-  constexpr int NST = ring_depth<DROP>::value;
+  constexpr int NST = ring_depth<PAIRS>::value;
   const uint32_t dseed = ns_eff_seed(p.drop_seed, p.seed_dev);   // wave-uniform: one scalar load at entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
   };
 
-  if constexpr (!DROP) {
+  if constexpr (PAIRS) {
     // ---- slices in pairs: pairs p + 1 in flight while pair p is multiplied, pair p + 2 requested into pair p - 1's slots behind the barrier
     // (slices past the end -- an odd count, a one-pair product -- arrive as zeros: issue() fetches the zero chunk for them)
     const int npairs = (nsteps + 1) >> 1;
@@ -245,6 +248,8 @@ __global__ __launch_bounds__(NTH, 2) void ns_gemm_ring_kernel(const ns_gemm_desc
 
 }  // namespace
 
+extern int g_ns_ab_flag;
+
 // called by ns_gemm() for NT descriptors with N > 96 and no A-operand dropout (arguments already validated)
 int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   const int tn = (d->N + BN - 1) / BN;
@@ -254,19 +259,30 @@ int ns_gemm_ring_launch(const ns_gemm_desc* d, hipStream_t st) {
   // columns = 88 tiles): such launches are bound by what ONE CU can fetch, and 176 workgroups move 3/4 of the bytes per CU
   const bool small = splits == 1 && tiles128 <= 384 && d->M > 64;
   const bool dropv = d->drop_p > 0.f;
-  const size_t lds = (size_t)(dropv ? ring_depth<true>::value : ring_depth<false>::value) * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
+  // Slices in pairs (six-deep ring) halve the synchronisation points of a workgroup but cost LDS: 72 KiB for the 64-row tile (two workgroups per
+  // CU instead of three), 96 KiB for the 128-row tile (ONE instead of two).  Measured in round 6 (tools/probe/ring_depth_ab.py,
+  // profiles/r6_probe_ring_depth.log): the 128-row tile is 11-26 % FASTER with four single slices on every shape (the split-K
+  // LM-head input gradient 307 -> 264 us), the 64-row tile is 8-18 % faster in pairs while a CU holds at most ~3 of its workgroups
+  // (2 816 rows x N <= 1024: 8.8 against 9.7 us at N = K = 512, 21.6 / 25.5 at K = 2048) and 7-10 % slower beyond (N = 1536 / 2048:
+  // 1 056 / 1 408 workgroups, where the third resident workgroup counts).  A/B flags 1 / 2 invert the choice for the 128- / 64-row tile.
+  const int tiles64 = ((d->M + 63) / 64) * tn;
+  const bool pairs = !dropv && (small ? ((tiles64 < 1024) != ((g_ns_ab_flag & 2) != 0)) : (g_ns_ab_flag & 1) != 0);
+  const size_t lds = (size_t)(pairs ? 6 : 4) * (size_t)((small ? 64 : 128) * BKS * 2 + B_BYTES);
   static ns_dev_once attr_once;      // kernel attributes, once per device (ns_common.h)
-  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_ring_kernel<false, 128>, (const void*)ns_gemm_ring_kernel<true, 128>,
-                                   (const void*)ns_gemm_ring_kernel<false, 64>, (const void*)ns_gemm_ring_kernel<true, 64>},
+  if (!ns_dyn_lds_once(attr_once, {(const void*)ns_gemm_ring_kernel<false, 128, true>, (const void*)ns_gemm_ring_kernel<false, 128, false>,
+                                   (const void*)ns_gemm_ring_kernel<true, 128, false>, (const void*)ns_gemm_ring_kernel<false, 64, true>,
+                                   (const void*)ns_gemm_ring_kernel<false, 64, false>, (const void*)ns_gemm_ring_kernel<true, 64, false>},
                        96 * 1024, "ns_gemm (ring)"))
     return NS_ERR_HIP;
   if (small) {
     const int tiles = ((d->M + 63) / 64) * tn;
-    if (d->drop_p > 0.f) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 64>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
-    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 64>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
+    if (dropv) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 64, false>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
+    else if (pairs) hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 64, true>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
+    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 64, false>), dim3(tiles, 1), dim3(NTH), lds, st, *d);
   } else {
-    if (d->drop_p > 0.f) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 128>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
-    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 128>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
+    if (dropv) hipLaunchKernelGGL((ns_gemm_ring_kernel<true, 128, false>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
+    else if (pairs) hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 128, true>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
+    else hipLaunchKernelGGL((ns_gemm_ring_kernel<false, 128, false>), dim3(tiles128, splits), dim3(NTH), lds, st, *d);
   }
   return 0;
 }

@@ -126,6 +126,8 @@ class Generator:
             finally:
                 self.use_lists, self.use_graph, self.cache_sessions = saved
             self.last_loop_mode = mode
+            if ref.shape != out.shape:
+                raise RuntimeError(f"NS_LISTS_VERIFY: replayed launch lists ({mode}) gave ids of shape {tuple(out.shape)}, eager launches {tuple(ref.shape)}")
             if not torch.equal(ref, out):
                 bad = (ref != out).any(dim=1).nonzero().flatten().tolist()
                 raise RuntimeError(f"NS_LISTS_VERIFY: replayed launch lists ({mode}) and eager launches disagree on rows {bad[:8]}")
