@@ -128,7 +128,34 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
   const ns_u4v rsrc_k = {(uint32_t)(uintptr_t)K, (uint32_t)((uintptr_t)K >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
   const ns_u4v rsrc_v = {(uint32_t)(uintptr_t)V, (uint32_t)((uintptr_t)V >> 32) & 0xffffu, 0x80000000u, 0x00020000u};
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  // The forward is bound by VALU ISSUE (round 6 counters, profiles/r6_pmc_attn_fwd.log: 87 % of the SIMDs' vector-issue cycles, the matrix
+  // pipe 47 % busy), so everything a tile can do WITHOUT a vector instruction leaves the vector stream: the per-lane part of a piece's source
+  // offset is computed once (row inside the tile, swizzled chunk), the tile's position rides in the buffer load's SCALAR offset.  Only the last
+  // tile of a sequence whose length is not a multiple of 64 clamps rows (keys past Lk repeat row Lk - 1, masked below) and pays the four 32-bit
+  // multiplies (quarter rate) + adds per tile that every tile paid before.
+  uint32_t voff_k[2], voff_v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = 2 * wave + j;
+    const int row = 8 * piece + ((lane >> 2) & 7);
+    const int chunk = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));
+    voff_k[j] = 2u * ((uint32_t)row * (uint32_t)p.ldk + chunk * 8);
+    voff_v[j] = 2u * ((uint32_t)row * (uint32_t)p.ldv + chunk * 8);
+  }
   auto dma_tile = [&](int buf, int k0) __attribute__((always_inline)) {
+    if (k0 + 64 <= p.Lk) {
+      const uint32_t so_k = 2u * (uint32_t)k0 * (uint32_t)p.ldk, so_v = 2u * (uint32_t)k0 * (uint32_t)p.ldv;     // wave-uniform: scalar multiplies
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t dst = smem_base + (uint32_t)(buf * 16384 + (2 * wave + j) * 1024);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %7 offen lds\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %8 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(dst), "s"(dst + 8192u), "v"(voff_k[j]), "v"(voff_v[j]), "s"(rsrc_k), "s"(rsrc_v), "s"(so_k), "s"(so_v)
+                     : "memory");
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece = 2 * wave + j;
@@ -171,10 +198,18 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
     for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // K fragment addresses (same reason): lds_off(kt * 32 + lr, 2 s + lh) = [1024 (lr >> 3) + 64 (lr & 7)] + 16 ((2 (s & 1) + lh) ^ ((lr >> 2) & 3))
+  // + 4096 kt + 512 (s >> 1): the swizzle term takes TWO values per lane (s even / odd: x and x ^ 32), the rest are immediates of the read --
+  // two address registers and one add per tile for the buffer instead of an address computation per read
+  const int kf_base = 1024 * (lr >> 3) + 64 * (lr & 7);
+  const int kf_x = 16 * (lh ^ ((lr >> 2) & 3));
+  const int kf_off[2] = {kf_base + kf_x, kf_base + (kf_x ^ 32)};
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * 64;
     const char* const Ks = smem + (t & 1) * 16384;
     const char* const Vs = Ks + 8192;
+    const char* const kf0 = Ks + kf_off[0];
+    const char* const kf1 = Ks + kf_off[1];
     // this wave's pieces of tile t are in; behind the barrier everyone's are, and every wave is through tile t - 1 (the other pair is free)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const ns_
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const half8 a = *(const half8*)(Ks + lds_off(kt * 32 + lr, 2 * s + lh));
+        const half8 a = *(const half8*)(((s & 1) ? kf1 : kf0) + 4096 * kt + 512 * (s >> 1));
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], st[kt], 0, 0, 0);
       }
     }
