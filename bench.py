@@ -33,14 +33,14 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 # ns_gemm_p8*_kernel rows together.  Since round 5 the class has 52 launches per step (68 before): out_proj + LayerNorm run as ns_gemm_ln
 # ("rowln" in step_share), the six decoder layers' cross K|V projections and their input gradients as one launch each
 DOMINANT = "ns_gemm_p8_kernel+ns_gemm_p8s_kernel"
-PMC_FILE = "profiles/r5_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
-DECODE_PMC_FILE = "profiles/r5_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
+PMC_FILE = "profiles/r6_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh pmc), hash-guarded
+DECODE_PMC_FILE = "profiles/r6_decode_pmc_traffic.json"   # the same two passes over tools/bench_decode.py (tools/profile.sh decode_pmc)
 LV2_GFLOP_PER_SAMPLE = 5630.0   # whisper-large-v2, 273-ch, fwd+bwd
 # round 6: the external yardstick (tools/probe/vendor_yardstick.py -> profiles/r6_yardstick.json): the MFMA rate and HBM rate this chip HOLDS.
 # `frac` stays against the spec peaks (2.5 PFLOP/s, 8 TB/s); `frac_of_sustained` is reported BESIDE it, never instead of it.
 YARDSTICK_FILE = "profiles/r6_yardstick.json"
 HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6300.0      # spec; float4 copy (MI355X_MICROARCH.md)
-SQ_FILE = "profiles/r5_pmc_SQ_by_kernel.tsv"
+SQ_FILE = "profiles/r6_pmc_SQ_by_kernel.tsv"
 
 
 def sustained_mfma_tflops():

@@ -187,7 +187,7 @@ def test_split_k_atomics_are_not_serialised(tmp_path):
     With the load next to its use every global_atomic_add_f32 sat behind its own s_waitcnt vmcnt(0), i.e. behind the completion
     of all atomics before it."""
     ks = {k: v for k, v in _kernels(_asm("ns_gemm_ring.hip", tmp_path)).items() if "ns_gemm_ring_kernel" in k}
-    assert len(ks) == 4
+    assert len(ks) == 6      # {128, 64}-row tile x {pairs, single slices} + the two dropout forms (round 6: the ring depth is chosen per launch)
     for name, body in ks.items():
         lines = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
         n_at = sum(1 for l in lines if l.startswith("global_atomic_add_f32"))
