@@ -1085,6 +1085,15 @@ class MegWhisperEngine:
                     ops.adalora_fold_grads(tmp[g], self.pview(k + ".lora_B"), (self.pview(en), eoff), self.gview(k + ".lora_B"),
                                            (self.gview(en), eoff), N, r, alphas[g])
             return
+        if G > 1 and not self.adalora and not self.no_fused_lora_bwd and ops.lora_bwd_supported(N, r, 1):
+            # a stacked site whose G-group form is not built (whisper-large-v2's q | k | v: three groups of 1280 columns would need 240
+            # accumulator registers per thread) runs the fused kernel once per GROUP on that group's columns of dy / u / du: the same bytes
+            # of dy in total, three launches instead of three down-projection GEMMs + three weight-gradient GEMMs (round 6: 3 x 77 us
+            # against 3 x 57 + 3 x 90 us per layer, profiles/r6_large_v2_kernel_stats.csv)
+            for g, k in enumerate(keys):
+                ops.lora_bwd_dudb(dy=(dy16, g * N), ldy=ldy, u=(u16, g * r), ldu=G * r, du=(du16, g * r), lddu=G * r, sBT=[sBT[g]],
+                                  dB=[self.gview(k + ".lora_B")], lddb=r, M=M, N=N, r=r, alpha_du=self._drop_inv(), alpha_db=[alphas[g]])
+            return
         for g, k in enumerate(keys):
             self._gemm(A=(dy16, g * N) if G > 1 else dy16, am=rowmap(ldy), K=N, B=sBT[g], ldb=N, M=M, N=r,
                      C16=(du16, g * r) if G > 1 else du16, c16m=rowmap(G * r), alpha=self._drop_inv())

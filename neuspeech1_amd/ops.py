@@ -527,14 +527,15 @@ def lora_bwd_dudb(*, dy, ldy, u, ldu, du, lddu, sBT, dB, lddb, M, N, r, alpha_du
     """sBT / dB / alpha_db: one entry per column group of dy (q | k | v: three, else one).  slabs: dB partials through a
     workspace + reduce launch (one cached workspace per device, sized for the largest request) instead of fp32 atomics"""
     d = L.LoraBwdDesc()
+    dev = (du[0] if isinstance(du, tuple) else du).device      # (tensor, element offset) pairs address a column group of a stacked buffer
     if slabs:
         need = L.load().ns_lora_bwd_workspace_bytes(M, N, len(sBT), splits)
-        ws = _lora_ws.get(du.device)
+        ws = _lora_ws.get(dev)
         if ws is None or ws.numel() < need:
             if ws is not None:
                 _retired_ws.append(ws)
-            ws = torch.empty(need, device=du.device, dtype=torch.uint8)
-            _lora_ws[du.device] = ws
+            ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            _lora_ws[dev] = ws
         d.workspace, d.workspace_bytes = ptr(ws), ws.numel()
     d.dy, d.u, d.du = ptr(dy), ptr(u), ptr(du)
     G = len(sBT)
