@@ -131,3 +131,66 @@ def test_loader_workers_come_from_a_forkserver_and_do_not_reimport_the_callers_s
     assert out.count("MAIN BODY RUNS") == 1, out
     assert "EPOCH 0 10" in out and "EPOCH 1 10" in out and "REFUSED DataLoader workers must come from" in out and "FILE True" in out, out
     assert "LOCAL True" in out, out      # objects defined in the main script are named up front, not by a pickling error inside a worker
+
+
+def test_feed_cache_files_hold_the_collator_and_autocast_roundings(tmp_path):
+    """neuspeech1_amd.feed.plan_cached (round 6, host logic only): the cache file of a recording holds round16(round32(x)) (f16) or round32(x)
+    (f32) of exactly the rows / samples the plain plan would stage -- channel slice, crop of recordings longer than 2 T --, is reused by a
+    second plan, is rebuilt when the source file changes, is skipped where nothing narrower exists (float16 sources, f32 sources with an f32
+    cache, exotic dtypes that numpy loads), and two builders racing for one file both leave a complete file."""
+    import os
+    import threading
+    import numpy as np
+    from neuspeech1_amd.feed import NS_FEED_F16, NS_FEED_F32, RawSignal, _fill, cache_path, plan_cached, plan_read
+    rng = np.random.default_rng(3)
+    T, cdir = 600, str(tmp_path / "cache")
+    a = rng.standard_normal((30, 500)) * 1e3
+    a[0, :4] = [1e-8, 70000.0, -1e-30, 65504.0]          # fp16 subnormal / overflow / underflow / largest finite
+    p = str(tmp_path / "a.npy")
+    np.save(p, a)
+    raw = RawSignal(p, 4, 24, 20)
+    for dt, code, np_t in (("f16", NS_FEED_F16, np.float16), ("f32", NS_FEED_F32, np.float32)):
+        pl = plan_cached(raw, T, cdir, dt)
+        want = a[4:24].astype(np.float32)
+        with np.errstate(over="ignore"):
+            want = want.astype(np_t)
+        got = np.load(pl.path)
+        assert pl.kind == "span" and pl.dtype == code and (pl.rows, pl.n) == (20, 500) and got.dtype == np_t
+        assert np.array_equal(got.view(np.uint16 if dt == "f16" else np.uint32), want.view(np.uint16 if dt == "f16" else np.uint32))
+        buf = bytearray(pl.nbytes)
+        _fill(pl, memoryview(buf))
+        assert bytes(buf) == want.tobytes()
+        m0 = os.stat(pl.path).st_mtime_ns
+        assert plan_cached(raw, T, cdir, dt).path == pl.path and os.stat(pl.path).st_mtime_ns == m0      # reused, not rebuilt
+    # a recording longer than 2 T: only the first T samples of each row are cached
+    b = rng.standard_normal((20, 3 * T + 7))
+    pb = str(tmp_path / "b.npy")
+    np.save(pb, b)
+    pl = plan_cached(RawSignal(pb, 0, 20, 20), T, cdir, "f16")
+    assert np.array_equal(np.load(pl.path), b[:, :T].astype(np.float32).astype(np.float16))
+    # the source changes: a new cache file (size / mtime are part of its name)
+    old = cache_path(cdir, raw, T, "f16")
+    np.save(p, a * 2.0)
+    os.utime(p, ns=(os.stat(p).st_atime_ns, os.stat(p).st_mtime_ns + 5_000_000))
+    pl2 = plan_cached(raw, T, cdir, "f16")
+    assert pl2.path != old and np.array_equal(np.load(pl2.path), (a[4:24] * 2.0).astype(np.float32).astype(np.float16))
+    # nothing narrower to store: the plain plan comes back
+    h = str(tmp_path / "h.npy")
+    np.save(h, rng.standard_normal((20, 100)).astype(np.float16))
+    f = str(tmp_path / "f.npy")
+    np.save(f, rng.standard_normal((20, 100)).astype(np.float32))
+    i16 = str(tmp_path / "i.npy")
+    np.save(i16, rng.integers(-5, 5, (20, 100)).astype(np.int16))
+    assert plan_cached(RawSignal(h, 0, 20, 20), T, cdir, "f16").path == h
+    assert plan_cached(RawSignal(f, 0, 20, 20), T, cdir, "f32").path == f
+    assert plan_cached(RawSignal(f, 0, 20, 20), T, cdir, "f16").path != f
+    assert plan_cached(RawSignal(i16, 0, 20, 20), T, cdir, "f16").kind == "array" == plan_read(RawSignal(i16, 0, 20, 20), T).kind
+    # two ranks touch a new recording at once
+    c = str(tmp_path / "c.npy")
+    np.save(c, rng.standard_normal((20, 400)))
+    res = []
+    ths = [threading.Thread(target=lambda: res.append(plan_cached(RawSignal(c, 0, 20, 20), T, cdir, "f16"))) for _ in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert len({r.path for r in res}) == 1 and np.load(res[0].path).shape == (20, 400)
+    assert not [f_ for f_ in os.listdir(cdir) if ".tmp." in f_]
