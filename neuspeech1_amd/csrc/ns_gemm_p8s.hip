@@ -97,8 +97,20 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, const T& v) 
 #define NS_STAMP(i) do { } while (0)
 #endif
 
-template <bool DROP, int KIND, bool K2LDS>
+// WP ("wave-private" epilogue, round 6; PLAIN launches without a side product): every wave reads back and stores exactly the 64 x 64 block of
+// the staged half that IT wrote (8 rows x 128 B per wave instruction instead of 2 rows x 512 B), so staging and storing need no workgroup
+// barrier between them -- a wave's own LDS traffic is ordered by s_waitcnt lgkmcnt(0) -- and none between the halves.  In-kernel stamps of the
+// barrier form at K = 512 (profiles/r6_probe_p8s_stamps.log): stage 3.7 k + finish 3.6 k + stage 1.5 k + finish 3.2 k = 12 k of a 37 k-cycle tile,
+// the two finish phases paced by the rate the CU's store path accepts 1-KiB store instructions (~19 B per cycle: tools/probe/store_burst.hip),
+// every wave in the same phase.  Without the barriers the waves drift apart and one wave's conversions run under another's stores: measured
+// (tools/probe/wp_epilogue_ab.py, profiles/r6_probe_wp_epilogue.log, outputs bitwise equal) -4 % on the stacked cross K|V launch, the conv GELU
+// launches and the K = 512 dgrads, -1 % on q|k|v, level on the K >= 1536 dgrads and on the gelu'-multiply form (which therefore keeps the
+// barrier form: no instantiation is built for it).  What is left of the finish phases is the store path itself: a CU's 128 KiB take 6.5 k
+// cycles when every CU stores at once and 3.7 k when half of them do (tools/probe/store_burst.hip); the persistent kernel's CUs run their
+// equal tiles nearly in phase.
+template <bool DROP, int KIND, bool K2LDS, bool WP>
 __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_in) {
+  static_assert(!WP || KIND == NS_EPI_PLAIN, "the fp32-residual (HBM-bound) and gelu'-multiply (no gain measured) epilogues keep the barrier form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef NS_P8_STAMPS
@@ -126,6 +138,18 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     ti = bid >> 3;
   }
   if (ti >= xcount) return;
+  // Start-up stagger (round 6, the gelu'-multiply launches of >= 8 tiles per CU only).  One workgroup per CU walks equal tiles, so the CUs stay in
+  // phase and their epilogues -- here 128 KiB of pre-activation loads + 128 KiB of stores per tile -- hit the fabric together: a CU's 128 KiB
+  // of stores take 6.5 k cycles when every CU stores at once and 3.7 k when half of them do (tools/probe/store_burst.hip).  Workgroup group
+  // g = (id >> 3) & 3 starts g * splits / 4 cycles late (`splits`, unused by this form otherwise, carries the spread: the launcher).  Measured
+  // (tools/probe/p8s_stagger_ab.py, profiles/r6_probe_p8s_stagger.log; spread 0 / 8 k / 16 k / 24 k / 40 k cycles): fc2 dgrad x gelu' 280.7 /
+  // 275.1 / 268.5 / 266.5 / 266.1 us; the other epilogue kinds do not gain (q|k|v level, GELU +2 %, fp32 residual +3..6 %), so only this kind
+  // does it.  Timing only: results are bit-identical.
+  if (KIND == NS_EPI_DGELU && p.splits > 1) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dl = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)p.splits / 4ull;
+    while (__builtin_amdgcn_s_memtime() - t0 < dl) __builtin_amdgcn_s_sleep(8);
+  }
 
   const int nsteps = (p.K + BK - 1) / BK;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x80000000u, 0x00020000);
@@ -428,7 +452,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, l15e = lane_e & 15, lge = lane_e >> 4;
-    const int ecg = tid_e & 31, er0 = tid_e >> 5;
+    // barrier form: thread = (16-B column chunk ecg of the 512-B row, row er0 + 16 i); WP: the wave's own block, lane = (row (lane >> 3) + 8 i of
+    // its 64 rows, chunk wn * 8 + (lane & 7))
+    const int ecg = WP ? wn * 8 + (lane_e & 7) : (tid_e & 31), er0 = WP ? wm * 64 + (lane_e >> 3) : (tid_e >> 5);
     ns_rowmap c16m = p.c16m, g16m = p.g16m, p16m = p.p16m, h32m = p.h32m;
     int pos_rows = p.pos_rows;
     asm volatile("" : "+s"(c16m.seg_rows), "+s"(g16m.seg_rows), "+s"(p16m.seg_rows), "+s"(h32m.seg_rows), "+s"(pos_rows));
@@ -447,7 +473,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     const half_t* const P16 = (const half_t*)p.P16;
     const bool do_gelu = p.flags & NS_GEMM_GELU;
     const bool save_grad = p.flags & NS_GEMM_GELU_SAVE_GRAD, mulp = p.flags & NS_GEMM_MUL_P16;
-    const bool side = KIND == NS_EPI_PLAIN && p.side_B != nullptr;
+    const bool side = !WP && KIND == NS_EPI_PLAIN && p.side_B != nullptr;
     const uint32_t side_thr = (side && p.side_drop_p > 0.f) ? ns_drop_thr8(p.side_drop_p) : 0u;
     const uint32_t side_dseed = side_thr ? ns_eff_seed(p.side_drop_seed, p.seed_dev) : 0u;
     f32x4 res[KIND == NS_EPI_RES ? 8 : 1][2];     // one half at a time (the half-1 rows are requested when half 0's are consumed)
@@ -461,10 +487,13 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
       }
     // this thread's rows of half hh: staged row er0 + 16 i (er0 < 16) = tile row hh * 64 + er0 + rowc(i), rowc(i) = (i >> 2) * 128 + 16 * (i & 3)
     // a compile-time constant: offsets walk from the first row's (rm_walk) instead of being re-derived row by row
-    auto rowc = [](int i) __attribute__((always_inline)) { return (i >> 2) * 128 + 16 * (i & 3); };
+    // (WP: staged row er0 + 8 i, er0 = wm * 64 + (lane >> 3) = tile row wm * 128 + hh * 64 + (lane >> 3) + 8 i)
+    auto rowc = [](int i) __attribute__((always_inline)) { return WP ? 8 * i : (i >> 2) * 128 + 16 * (i & 3); };
     auto grow = [&](int hh, int rl) __attribute__((always_inline)) { return m0 + ((rl >> 6) << 7) + hh * 64 + (rl & 63); };
+    const int erow0 = WP ? wm * 128 + (lane_e >> 3) : er0;      // tile row (within a half) of this thread's first row
+    constexpr int RSTEP = WP ? 8 : 16;                          // staged rows between this thread's consecutive rows
     auto prefetch = [&](int hh) __attribute__((always_inline)) {
-      const int row0 = m0 + hh * 64 + er0;
+      const int row0 = m0 + hh * 64 + erow0;
       rm_walk wk;
       wk.init(KIND == NS_EPI_RES ? h32m : p16m, min(row0, p.M - 1));
 #pragma unroll
@@ -508,11 +537,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           const half4 va = *(const half4*)(hs + (er0 + 16 * i) * LDH + ecg * 8), vb = *(const half4*)(hs + (er0 + 16 * i) * LDH + 256 + ecg * 8);
           vst[i] = half8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
         } else {
-          vst[i] = *(const half8*)(hs + (er0 + 16 * i) * LDH + ecg * 16);
+          vst[i] = *(const half8*)(hs + (er0 + RSTEP * i) * LDH + ecg * 16);
         }
       }
       // offsets of this thread's first row of the half in every destination, walked row by row below
-      const int frow0 = m0 + hh * 64 + er0;
+      const int frow0 = m0 + hh * 64 + erow0;
       rm_walk wc, wg, wh;
       if (C16) wc.init(c16m, min(frow0, p.M - 1));
       if (G16) wg.init(g16m, min(frow0, p.M - 1));
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
           if (KIND != NS_EPI_RES && do_gelu) {
             if ((i & 1) == wm) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
           }
-          const int rl = er0 + 16 * i, row = frow0 + rowc(i);
+          const int rl = er0 + RSTEP * i, row = frow0 + rowc(i);
           if (!(KIND == NS_EPI_RES ? rokA : ecolok) || row >= p.M) continue;
           half8 v = vst[i];
           if (KIND == NS_EPI_DGELU) {
@@ -640,7 +669,7 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     }
     if (KIND != NS_EPI_RES) prefetch(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    NS_P8_BARRIER();
+    if (!WP) NS_P8_BARRIER();       // (WP: the wave reads back only what it wrote itself)
     NS_STAMP(3);
     // half 0's loads are older than the next tile's pieces and half 1's loads: settle them by count
     if (KIND == NS_EPI_RES) {
@@ -658,11 +687,11 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     finish_half(0);
     NS_STAMP(4);
     if (KIND == NS_EPI_RES) prefetch(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    NS_P8_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (WP: this wave's reads of half 0 are done before it overwrites its block)
+    if (!WP) NS_P8_BARRIER();
     stage_half(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    NS_P8_BARRIER();
+    if (!WP) NS_P8_BARRIER();
     NS_STAMP(5);
     if (KIND == NS_EPI_RES) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -686,16 +715,24 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
   }
 }
 
+}  // namespace
+extern int g_ns_ab_flag;      // A/B flag 4: the barrier form of the epilogue everywhere (tools/probe)
+namespace {
+
 template <bool DROP, bool K2LDS>
 void launch_kind(const ns_gemm_desc* d, int grid, hipStream_t st) {
   const int kind = d->H32 ? NS_EPI_RES : ((d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) ? NS_EPI_DGELU : NS_EPI_PLAIN);
-  if (kind == NS_EPI_RES) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_RES, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
-  else if (kind == NS_EPI_DGELU) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_DGELU, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
-  else hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN, K2LDS>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  const bool wp = !(g_ns_ab_flag & 4) && !d->side_B;
+  if (kind == NS_EPI_RES) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_RES, K2LDS, false>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else if (kind == NS_EPI_DGELU) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_DGELU, K2LDS, false>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  else {
+    if (wp) hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN, K2LDS, true>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+    else hipLaunchKernelGGL((ns_gemm_p8s_kernel<DROP, NS_EPI_PLAIN, K2LDS, false>), dim3(grid), dim3(NTH), LDS_BYTES, st, *d);
+  }
 }
 
-template <bool DROP, int KIND, bool K2LDS>
-const void* kfn() { return (const void*)ns_gemm_p8s_kernel<DROP, KIND, K2LDS>; }
+template <bool DROP, int KIND, bool K2LDS, bool WP = false>
+const void* kfn() { return (const void*)ns_gemm_p8s_kernel<DROP, KIND, K2LDS, WP>; }
 
 }  // namespace
 
@@ -722,7 +759,9 @@ int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st) {
                        {kfn<false, NS_EPI_PLAIN, false>(), kfn<false, NS_EPI_RES, false>(), kfn<false, NS_EPI_DGELU, false>(),
                         kfn<true, NS_EPI_PLAIN, false>(), kfn<true, NS_EPI_RES, false>(), kfn<true, NS_EPI_DGELU, false>(),
                         kfn<false, NS_EPI_PLAIN, true>(), kfn<false, NS_EPI_RES, true>(), kfn<false, NS_EPI_DGELU, true>(),
-                        kfn<true, NS_EPI_PLAIN, true>(), kfn<true, NS_EPI_RES, true>(), kfn<true, NS_EPI_DGELU, true>()},
+                        kfn<true, NS_EPI_PLAIN, true>(), kfn<true, NS_EPI_RES, true>(), kfn<true, NS_EPI_DGELU, true>(),
+                        kfn<false, NS_EPI_PLAIN, false, true>(), kfn<true, NS_EPI_PLAIN, false, true>(), kfn<false, NS_EPI_PLAIN, true, true>(),
+                        kfn<true, NS_EPI_PLAIN, true, true>()},
                        LDS_BYTES, "ns_gemm (p8s)"))
     return NS_ERR_HIP;
   static std::once_flag cu_once;     // every device of a node is the same part: the CU count is read once
@@ -735,6 +774,11 @@ int ns_gemm_p8s_launch(const ns_gemm_desc* d, hipStream_t st) {
   // one workgroup per CU (148 KiB of LDS, 512 threads x 256 registers: nothing else fits beside it), 8 XCDs round-robin
   const int per_xcd = std::min(cus_per_xcd, (tiles + 7) / 8);
   const bool k2lds = d->K2 > 0 && (d->a2_ngroup == 0 || d->a2_ngroup % BN == 0);   // one column group per tile: the LDS form of the second product
+  ns_gemm_desc dd = *d;
+  dd.splits = 1;
+  if ((d->flags & (NS_GEMM_DGELU | NS_GEMM_MUL_P16)) && !d->H32 && tiles >= 8 * 8 * cus_per_xcd && !(g_ns_ab_flag & 8))
+    dd.splits = 24000;      // the start-up stagger of the gelu'-multiply form (see the kernel); A/B flag 8 = off
+  d = &dd;
   if (d->drop_p > 0.f) { if (k2lds) launch_kind<true, true>(d, 8 * per_xcd, st); else launch_kind<true, false>(d, 8 * per_xcd, st); }
   else { if (k2lds) launch_kind<false, true>(d, 8 * per_xcd, st); else launch_kind<false, false>(d, 8 * per_xcd, st); }
   return 0;
