@@ -19,11 +19,19 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (cross-compiles gfx950 without a GPU)")
 
 
+_ASM_CACHE = {}
+
+
 def _asm(src, tmp_path):
-    out = str(tmp_path / (src + ".s"))
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-ffp-contract=fast", "-S",
-                    "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, capture_output=True)
-    return open(out).read()
+    """gfx950 assembly of one source, compiled once per test session (ns_gemm_p8s.hip takes ~20 s and several tests read it)"""
+    path = os.path.join(CSRC, src)
+    key = (src, os.path.getmtime(path), os.path.getmtime(os.path.join(CSRC, "ns_common.h")), os.path.getmtime(os.path.join(CSRC, "ns_gemm_epi.h")))
+    if key not in _ASM_CACHE:
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-ffp-contract=fast", "-S",
+                        "--cuda-device-only", path, "-o", out], check=True, capture_output=True)
+        _ASM_CACHE[key] = open(out).read()
+    return _ASM_CACHE[key]
 
 
 def _kernels(asm):
