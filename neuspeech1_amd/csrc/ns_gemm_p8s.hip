@@ -106,8 +106,8 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, const T& v) 
 // (tools/probe/wp_epilogue_ab.py, profiles/r6_probe_wp_epilogue.log, outputs bitwise equal) -4 % on the stacked cross K|V launch, the conv GELU
 // launches and the K = 512 dgrads, -1 % on q|k|v, level on the K >= 1536 dgrads and on the gelu'-multiply form (which therefore keeps the
 // barrier form: no instantiation is built for it).  What is left of the finish phases is the store path itself: a CU's 128 KiB take 6.5 k
-// cycles when every CU stores at once and 3.7 k when half of them do (tools/probe/store_burst.hip); the persistent kernel's CUs run their
-// equal tiles nearly in phase.
+// cycles when every CU stores at once and 3.7 k when half of them do (tools/probe/store_burst.hip), and inside this kernel the storing CU
+// shares its L2 with every other CU's operand stream.
 template <bool DROP, int KIND, bool K2LDS, bool WP>
 __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_in) {
   static_assert(!WP || KIND == NS_EPI_PLAIN, "the fp32-residual (HBM-bound) and gelu'-multiply (no gain measured) epilogues keep the barrier form");
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(NTH) void ns_gemm_p8s_kernel(const ns_gemm_desc p_i
     ti = bid >> 3;
   }
   if (ti >= xcount) return;
-  // Start-up stagger (round 6, the gelu'-multiply launches of >= 8 tiles per CU only).  One workgroup per CU walks equal tiles, so the CUs stay in
-  // phase and their epilogues -- here 128 KiB of pre-activation loads + 128 KiB of stores per tile -- hit the fabric together: a CU's 128 KiB
+  // Start-up stagger (round 6, the gelu'-multiply launches of >= 8 tiles per CU only).  One workgroup per CU walks equal tiles from a common start, so
+  // the first epilogues -- here 128 KiB of pre-activation loads + 128 KiB of stores per tile -- hit the fabric together (later ones drift apart by
+  // the main loops' own spread): a CU's 128 KiB
   // of stores take 6.5 k cycles when every CU stores at once and 3.7 k when half of them do (tools/probe/store_burst.hip).  Workgroup group
   // g = (id >> 3) & 3 starts g * splits / 4 cycles late (`splits`, unused by this form otherwise, carries the spread: the launcher).  Measured
   // (tools/probe/p8s_stagger_ab.py, profiles/r6_probe_p8s_stagger.log; spread 0 / 8 k / 16 k / 24 k / 40 k cycles): fc2 dgrad x gelu' 280.7 /

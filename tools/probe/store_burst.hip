@@ -36,8 +36,9 @@ __global__ __launch_bounds__(512) void k(half_t* C, int N, int stride, int reps,
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-int main() {
-  const int N = 1536, reps = 16;
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 1536, reps = 16;
+  printf("row stride %d B (N = %d)\n", 2 * N, N);
   const size_t rows = (size_t)(256 * reps / (N / 256) + 1) * 256;
   half_t* C; unsigned long long* cyc;
   CK(hipMalloc(&C, rows * N * 2)); CK(hipMalloc(&cyc, 256 * 8));
