@@ -70,6 +70,24 @@ def test_finetune_then_evaluation_end_to_end(dev, tmp_path, adalora):
     evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
                      "--max_new_tokens=8", "--device_feed=False"] + common)
     assert open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).read() == hyp_adapter
+    # ... and so does the feed through its narrow-type cache (--feed_cache_dir, round 6): first run builds the cache files, second reads them
+    cdir = str(tmp_path / "feed_cache")
+    for _ in range(2):
+        evaluation.main([f"--test_data={jl}", "--model_path=synthetic:tiny", f"--lora_model={ck}", "--batch_size=4",
+                         "--max_new_tokens=8", f"--feed_cache_dir={cdir}", "--feed_cache_dtype=f16"] + common)
+        assert open(os.path.join(ck, "formal_test_resultsno_post_processing.jsonl")).read() == hyp_adapter
+    assert len([f for f in os.listdir(cdir) if f.endswith(".f16.npy")]) == 12
+    # training from the cache: the same losses as from the float64 files (bit-identical batches; the weight-gradient atomics reorder)
+    out2 = str(tmp_path / "out_cached")
+    finetune.main([f"--train_data={jl}", f"--test_data={jl}", "--base_model=synthetic:tiny", f"--output_dir={out2}",
+                   "--orig_sample_rate=200", f"--use_adalora={adalora}", "--fp16=True", "--num_train_epochs=2",
+                   "--per_device_train_batch_size=4", "--per_device_eval_batch_size=4", "--logging_steps=1",
+                   "--eval_steps=2", "--save_steps=2", "--warmup_steps=2", "--learning_rate=1e-3",
+                   "--augment_config_path=None", "--max_steps=6", f"--feed_cache_dir={cdir}"] + common)
+    logs2 = [json.loads(l) for l in open(os.path.join(out2, "synthetic_tiny", "train_log.jsonl"))]
+    assert len(logs2) == 6
+    for a, b in zip(logs, logs2):
+        assert abs(a["loss"] - b["loss"]) <= 2e-3 * max(1.0, abs(a["loss"])), (a, b)
 
 
 def test_finetune_first_layer_only_with_gradient_accumulation(dev, tmp_path):
