@@ -320,6 +320,12 @@ int suite() {
   bad += run<MODE>(96000, 1536, 512, true);    // q|k|v: A 98 MB streamed from HBM
   bad += run<MODE>(8192, 8192, 512, false);    // 1024 tiles, 8 MB + 8 MB
   bad += run<MODE>(96000, 512, 2048, false);   // fc2
+  bad += run<MODE>(96000, 512, 1536, false);   // q|k|v dgrad
+  bad += run<MODE>(96000, 3840, 1280, false);  // large-v2 q|k|v
+  bad += run<MODE>(96000, 1280, 1280, false);  // large-v2 out_proj
+  bad += run<MODE>(96000, 5120, 1280, false);  // large-v2 fc1
+  bad += run<MODE>(96000, 1280, 5120, false);  // large-v2 fc2
+  bad += run<MODE>(8192, 8192, 8192, false);   // the guide's shape
   return bad;
 }
 
