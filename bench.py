@@ -8,6 +8,12 @@ fp16 LoRA r=32 training step = forward + backward + RCCL gradient all-reduce + c
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Inputs are synthetic (B,208,6000) MEG
 tensors already resident in HBM; weights are seeded random-init of the whisper-base architecture.
+
+Beside the contract's keys the line carries: `roofline` (dominant GEMM class: achieved TFLOP/s by HIP events, `frac` of the 2.5 PFLOP/s spec peak and
+`frac_of_sustained` of the rate the chip holds on random operands, counter `traffic` against `algorithmic_bytes_per_launch`), `encoder_fwd_bwd`
+(the quantity north_star's 40 % target is stated on), `step_budget` (round 6: per kernel class and family -- launches, ms, algorithmic FLOP / bytes,
+achieved rates, floors at the spec and at the sustained rates, counter bytes, mfma_busy; their sum of floors against the step), `cpu_baseline`
+(+ `cpu_baseline_port`, `torch_rocm_reference_object`), `eval` (tokens/s, decode-step HBM roofline, first / steady call), `large_v2`, `dp` at N > 1.
 """
 import argparse
 import json

@@ -89,3 +89,23 @@ def test_sustained_peak_comes_from_the_committed_yardstick():
     import bench
     s = bench.sustained_mfma_tflops()
     assert s is not None and 1500.0 < s < 2300.0       # back-to-back 16x16x32 fp16 MFMAs on random operands: ~0.75 of the 2.5 PFLOP/s spec peak
+
+
+def test_encoder_ceiling_follows_from_the_committed_yardstick():
+    """profiles/r6_encoder_ceiling.json is what tools/probe/encoder_ceiling.py derives from profiles/r6_yardstick.json:
+    with the faster of {vendor, this library} on every MFMA launch of the encoder's forward + backward and everything else free, the floor is above
+    what north_star's 40 % MFMA target allows."""
+    import json
+    import runpy
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r6_encoder_ceiling.json")))
+    before = open(os.path.join(ROOT, "profiles", "r6_encoder_ceiling.json")).read()
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "probe", "encoder_ceiling.py"), run_name="__main__")
+        again = json.load(open(os.path.join(ROOT, "profiles", "r6_encoder_ceiling.json")))
+    finally:
+        open(os.path.join(ROOT, "profiles", "r6_encoder_ceiling.json"), "w").write(before)
+    assert again == committed
+    assert committed["floor_ms"] > committed["ms_allowed_by_40_percent"] > 13.0
+    assert 0.25 < committed["mfma_frac_at_floor"] < 0.40
+    kinds = {r["launch"]: r["kernel"] for r in committed["per_layer_us"]}
+    assert kinds["attention forward"] == "ns" and kinds["attention backward"] == "ns"      # ours is the faster attention in both directions
